@@ -1,0 +1,190 @@
+/*
+ * rr_hip.h -- C ABI of librr_hip.so, the MI355X (gfx950) hybrid-retrieval hot path.
+ *
+ * The reference (Ntropy86/review-recommender) is pure Python and has no FFI of
+ * its own; its boundary for this path is a set of Python callables (SURVEY.md
+ * section 8b).  Each entry point below names the reference callable it stands
+ * in for.  A Python front-end binds these with ctypes (INTEGRATION.md shows
+ * the stub); the product wrapper is review-recommender_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative RR_E_* code otherwise;
+ *     rr_last_error() returns a thread-local message for the last failure;
+ *   - the caller owns every host buffer (C-contiguous, sizes as documented);
+ *     the library owns device memory behind opaque handles;
+ *   - "h_" parameters are host pointers, "d_" parameters are device pointers
+ *     on the handle's device (e.g. a torch tensor's data_ptr(), used by the
+ *     multi-GPU exchange so RCCL can move the buffers without a host hop);
+ *   - rows are int64 indices into the index's row space; a shard created with
+ *     a row offset reports GLOBAL rows (local row + offset);
+ *   - handles may be used from several host threads; calls on one handle are
+ *     serialised by an internal mutex (Streamlit shares cached handles across
+ *     session threads: app/app_product_search.py:53,71,119).
+ *   - there is no CPU fallback anywhere behind this ABI.
+ */
+#ifndef RR_HIP_H
+#define RR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_OK            0
+#define RR_E_INVALID    -1   /* bad argument (shape, NULL, range) */
+#define RR_E_HIP        -2   /* a HIP runtime call failed */
+#define RR_E_NOMEM      -3
+#define RR_E_STATE      -4   /* handle not ready for this call (e.g. meta not set) */
+
+#define RR_DTYPE_F32     0
+#define RR_DTYPE_BF16    1   /* storage only; accumulation is always fp32 */
+
+#define RR_MAX_POOL   2048   /* upper bound for pool / k */
+#define RR_MAX_BATCH  1024
+#define RR_MAX_QTERMS   64   /* query tokens per query kept by the BM25 kernels */
+
+typedef struct rr_index rr_index;   /* dense matrix + per-row metadata of one shard */
+typedef struct rr_bm25  rr_bm25;    /* BM25 postings (CSR by term) + forward CSR by doc */
+
+const char* rr_last_error(void);
+int rr_version(void);
+int rr_device_count(int* out);
+
+/* ------------------------------------------------------------------ index */
+
+/* Device-resident copy of product_emb.npy (nlp/11_build_product_embeddings.py:82-85):
+ * n_rows x dim, row-major.  h_matrix may be NULL (fill later with
+ * rr_index_upload_rows / rr_index_adopt_device).  row_offset is added to every
+ * row this shard reports.  dim is padded internally to a multiple of 64. */
+int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim, int32_t dtype,
+                    int32_t device, int64_t row_offset, rr_index** out);
+int rr_index_upload_rows(rr_index* ix, int64_t first_row, int64_t n_rows, const void* h_rows);
+/* Use a caller-owned device matrix (n_rows x dim_padded(), already padded) without copying. */
+int rr_index_adopt_device(rr_index* ix, const void* d_matrix);
+int rr_index_dim_padded(const rr_index* ix, int32_t* out);
+/* l2_normalize (utils.py:40-44) of every row, in place on the device. */
+int rr_index_l2_normalize(rr_index* ix, float eps);
+/* n_reviews / avg_stars of product_emb_meta.parquet (nlp/11...:86-90), row-aligned,
+ * plus log1p(n_reviews) as numpy computes it (kept so the volume prior and trust
+ * reproduce the reference bit for bit).  avg_stars may hold NaN. */
+int rr_index_set_meta(rr_index* ix, const double* h_n_reviews, const double* h_avg_stars,
+                      const double* h_log1p_n);
+int rr_index_destroy(rr_index* ix);
+
+/* ------------------------------------------------------------ K1 dense top-k */
+
+/* cosine_similarity_search (utils.py:111-124; _cosine_pool app/app_product_search.py:192-195;
+ * cosine_search app/test.py:125-132), batched: for each of n_queries query vectors
+ * (n_queries x dim fp32, host) the top `pool` rows by dot product, ordered
+ * (score desc, row asc); pool is clamped to n_rows like utils.py:116-117 and the
+ * clamped value is written to *pool_out.  out_rows / out_scores: n_queries x pool. */
+int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_queries, int32_t pool,
+                  int64_t* h_out_rows, float* h_out_scores, int32_t* pool_out);
+/* Same with device-resident queries and outputs, asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the handle's own stream). */
+int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t pool,
+                      int64_t* d_out_rows, float* d_out_scores, void* stream);
+/* Timing of the last dense scan kernel on this handle (HIP events, ms). */
+int rr_index_last_scan_ms(rr_index* ix, float* out_ms);
+/* Every scan launch is bracketed by a HIP event pair on its stream (ring of 512).
+ * Drains the pairs recorded since the last call: total ms and launch count. */
+int rr_index_scan_stats(rr_index* ix, double* out_total_ms, int64_t* out_launches);
+
+/* ------------------------------------------------------------ K2 BM25 */
+
+/* BM25Okapi(corpus) of rank_bm25 as used at app/app_product_search.py:142 and
+ * app/test.py:156, over integer term ids.  Inputs (host):
+ *   post_indptr[n_terms+1], post_docs[nnz] (ascending per term), post_tf[nnz]
+ *   doc_indptr[n_docs+1],  doc_terms[nnz] (ascending per doc),  doc_tf[nnz]
+ *   doc_len[n_docs] (token count incl. duplicates), idf[n_terms] (float64, with
+ *   the epsilon floor already applied), avgdl, k1, b.
+ * doc ids are LOCAL rows of the shard; idf / avgdl are corpus-wide. */
+int rr_bm25_create(int32_t device, int64_t n_docs, int64_t n_terms, int64_t nnz,
+                   const int64_t* post_indptr, const int32_t* post_docs, const int32_t* post_tf,
+                   const int64_t* doc_indptr, const int32_t* doc_terms, const int32_t* doc_tf,
+                   const int32_t* doc_len, const double* idf, double avgdl, double k1, double b,
+                   int64_t row_offset, rr_bm25** out);
+/* Same, with every array already resident on `device` (caller-owned, not copied, must
+ * outlive the handle): used when the corpus is built on the GPU. */
+int rr_bm25_create_dev(int32_t device, int64_t n_docs, int64_t n_terms, int64_t nnz,
+                       const int64_t* d_post_indptr, const int32_t* d_post_docs, const int32_t* d_post_tf,
+                       const int64_t* d_doc_indptr, const int32_t* d_doc_terms, const int32_t* d_doc_tf,
+                       const int32_t* d_doc_len, const double* d_idf, double avgdl, double k1, double b,
+                       int64_t row_offset, rr_bm25** out);
+int rr_bm25_destroy(rr_bm25* bm);
+/* BM25Okapi.get_scores(tokens) (app/app_product_search.py:206): float64[n_docs],
+ * tokens applied in order, duplicates counted again, ids < 0 = unknown token. */
+int rr_bm25_get_scores(rr_bm25* bm, const int32_t* h_term_ids, int32_t n_terms_in_query,
+                       double* h_out_scores);
+/* _bm25_for_candidates (app/app_product_search.py:201-208) / bm25_scores (app/test.py:168-173)
+ * without the N-long intermediate: BM25 of each query at its candidate rows only.
+ *   h_term_ids[term_off[q] .. term_off[q+1]) are query q's token ids;
+ *   rows: n_queries x pool GLOBAL rows (rows outside this shard score 0);
+ *   out : n_queries x pool float32 (float64 accumulate, cast like np.float32).
+ * mode 0 = forward CSR (doc -> terms), mode 1 = postings lists (binary search). */
+int rr_bm25_scores_at(rr_bm25* bm, const int32_t* h_term_ids, const int32_t* h_term_off,
+                      int32_t n_queries, const int64_t* h_rows, int32_t pool, int32_t mode,
+                      float* h_out);
+int rr_bm25_scores_at_dev(rr_bm25* bm, const int32_t* d_term_ids, const int32_t* d_term_off,
+                          int32_t n_queries, const int64_t* d_rows, int32_t pool, int32_t mode,
+                          float* d_out, void* stream);
+
+/* ------------------------------------------------------------ K3 fuse + top-k */
+
+typedef struct rr_fuse_params {
+    double w_dense, w_bm25, w_rerank, w_prior, w_best;  /* run_search weights */
+    double prior_C;          /* Bayesian prior strength (prior_C) */
+    int32_t min_reviews;     /* trust ramp (min_reviews) */
+    int32_t trust_sat;       /* 80 in the app (app/app_product_search.py:303) */
+    int32_t apply_trust;     /* 1 = app flavour, 0 = CLI flavour (app/test.py:308) */
+    int32_t rerank_active;   /* 1 when rerank_k > 0: _rerank column is float32 */
+    int32_t rerank_k;        /* first rerank_k pool rows carry reranker scores */
+    int32_t k;               /* rows to return */
+    int32_t n_candidates;    /* candidates supplied per query (>= pool when merging shards) */
+    int32_t pool;            /* pool size to cut the candidates to before fusing */
+    int32_t cand_per_rank;   /* 0: candidate arrays are [query][n_candidates]; else the arrays are
+                                gathered shard payloads [rank][query][cand_per_rank] */
+    int32_t _pad;
+    int64_t cand_rank_stride_bytes; /* distance between two ranks' payload blocks */
+} rr_fuse_params;
+
+/* Everything run_search does after the candidate pool exists
+ * (app/app_product_search.py:256-312; CLI app/test.py:250-309): cut the
+ * n_candidates supplied per query to the best `pool` by (dense desc, row asc)
+ * [the shard merge], min-max of dense / bm25 / prior / rerank / best, Bayesian
+ * prior with the pool mean, volume prior, trust, weighted blend, gate, stable
+ * sort by final desc, first k.
+ * Candidate inputs, n_candidates per query (device pointers): rows, dense, bm25 raw
+ * (NULL = zeros), n_reviews, avg_stars, log1p_n (all three NULL = gathered from `ix`
+ * by row; required when merging shards).  Pool inputs, `pool` per query, aligned
+ * with the pool order this call produces (so a caller that needs them first calls
+ * with k = pool and reads out_rows): rerank raw, best raw (NULL = zeros), gate
+ * (NULL = ones).
+ * Outputs (device): out_rows[nq x pool] global rows in pool order;
+ * out_cols[nq x 8 x pool] = _dense,_bm25,_prior,_rerank,_best,_gate,_trust,_final (float64);
+ * out_order[nq x k] = pool positions of the top-k, best first. */
+int rr_fuse_topk_dev(rr_index* ix, const rr_fuse_params* p, int32_t n_queries,
+                     const int64_t* d_rows, const float* d_dense, const float* d_bm25,
+                     const double* d_n_reviews, const double* d_avg_stars, const double* d_log1p_n,
+                     const float* d_rerank, const float* d_best, const float* d_gate,
+                     int64_t* d_out_rows, double* d_out_cols, int32_t* d_out_order, void* stream);
+/* Host-buffer form of the same call. */
+int rr_fuse_topk(rr_index* ix, const rr_fuse_params* p, int32_t n_queries,
+                 const int64_t* h_rows, const float* h_dense, const float* h_bm25,
+                 const double* h_n_reviews, const double* h_avg_stars, const double* h_log1p_n,
+                 const float* h_rerank, const float* h_best, const float* h_gate,
+                 int64_t* h_out_rows, double* h_out_cols, int32_t* h_out_order);
+/* Gather per-row metadata for candidate rows (payload of the shard exchange). */
+int rr_index_gather_meta_dev(rr_index* ix, const int64_t* d_rows, int64_t n,
+                             double* d_n_reviews, double* d_avg_stars, double* d_log1p_n,
+                             void* stream);
+
+/* Stream helpers for callers that chain *_dev calls. */
+int rr_index_stream(rr_index* ix, void** out_stream);
+int rr_index_synchronize(rr_index* ix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RR_HIP_H */

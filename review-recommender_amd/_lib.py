@@ -1,0 +1,98 @@
+"""ctypes binding of librr_hip.so (include/rr_hip.h).  No CPU fallback: if the
+library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+from .build import LIB_PATH
+
+c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+P = C.POINTER
+
+
+class FuseParams(C.Structure):
+    """struct rr_fuse_params (include/rr_hip.h)."""
+    _fields_ = [("w_dense", c_f64), ("w_bm25", c_f64), ("w_rerank", c_f64),
+                ("w_prior", c_f64), ("w_best", c_f64), ("prior_C", c_f64),
+                ("min_reviews", c_i32), ("trust_sat", c_i32), ("apply_trust", c_i32),
+                ("rerank_active", c_i32), ("rerank_k", c_i32), ("k", c_i32),
+                ("n_candidates", c_i32), ("pool", c_i32), ("cand_per_rank", c_i32),
+                ("_pad", c_i32), ("cand_rank_stride_bytes", c_i64)]
+
+
+# name -> (restype, argtypes); every symbol include/rr_hip.h declares
+PROTOTYPES = {
+    "rr_last_error": (C.c_char_p, []),
+    "rr_version": (C.c_int, []),
+    "rr_device_count": (C.c_int, [P(C.c_int)]),
+    "rr_index_create": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, P(c_vp)]),
+    "rr_index_upload_rows": (C.c_int, [c_vp, c_i64, c_i64, c_vp]),
+    "rr_index_adopt_device": (C.c_int, [c_vp, c_vp]),
+    "rr_index_dim_padded": (C.c_int, [c_vp, P(c_i32)]),
+    "rr_index_l2_normalize": (C.c_int, [c_vp, c_f32]),
+    "rr_index_set_meta": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "rr_index_destroy": (C.c_int, [c_vp]),
+    "rr_dense_topk": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, P(c_i32)]),
+    "rr_dense_topk_dev": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "rr_index_last_scan_ms": (C.c_int, [c_vp, P(c_f32)]),
+    "rr_index_scan_stats": (C.c_int, [c_vp, P(c_f64), P(c_i64)]),
+    "rr_bm25_create": (C.c_int, [c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                 c_vp, c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, P(c_vp)]),
+    "rr_bm25_create_dev": (C.c_int, [c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                     c_vp, c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, P(c_vp)]),
+    "rr_bm25_destroy": (C.c_int, [c_vp]),
+    "rr_bm25_get_scores": (C.c_int, [c_vp, c_vp, c_i32, c_vp]),
+    "rr_bm25_scores_at": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp]),
+    "rr_bm25_scores_at_dev": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "rr_fuse_topk_dev": (C.c_int, [c_vp, P(FuseParams), c_i32] + [c_vp] * 9 + [c_vp] * 3 + [c_vp]),
+    "rr_fuse_topk": (C.c_int, [c_vp, P(FuseParams), c_i32] + [c_vp] * 9 + [c_vp] * 3),
+    "rr_index_gather_meta_dev": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "rr_index_stream": (C.c_int, [c_vp, P(c_vp)]),
+    "rr_index_synchronize": (C.c_int, [c_vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads librr_hip.so once and binds every prototype.  Raises if it is absent."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not LIB_PATH.exists():
+            raise HipLibraryError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    """Maps a non-zero status to ValueError (bad argument) or RuntimeError."""
+    if rc == 0:
+        return
+    msg = load().rr_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(f"{what}: {msg}" if what else msg)
+    raise HipLibraryError(f"{what}: {msg} (status {rc})" if what else f"{msg} (status {rc})")
+
+
+def ptr(a):
+    """Address of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array passed to the HIP library must be C-contiguous")
+    return a.ctypes.data_as(c_vp)

@@ -1,0 +1,173 @@
+// rr_api.hip -- handles, errors and data movement behind the C ABI (include/rr_hip.h).
+#include <stdarg.h>
+
+#include "rr_common.h"
+
+static thread_local char g_err[512] = "";
+
+void rr_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* rr_last_error(void) { return g_err; }
+extern "C" int rr_version(void) { return 100; }
+
+extern "C" int rr_device_count(int* out) {
+    RR_REQUIRE(out, "rr_device_count: NULL out");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out = 0;
+        rr_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return RR_E_HIP;
+    }
+    *out = n;
+    return RR_OK;
+}
+
+static size_t rr_elem_size(int dtype) { return dtype == RR_DTYPE_BF16 ? 2 : 4; }
+
+extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim, int32_t dtype,
+                               int32_t device, int64_t row_offset, rr_index** out) {
+    RR_REQUIRE(out, "rr_index_create: NULL out");
+    *out = nullptr;
+    RR_REQUIRE(n_rows >= 1 && n_rows < (1ll << 31), "rr_index_create: n_rows %lld out of [1, 2^31)",
+               (long long)n_rows);
+    RR_REQUIRE(dim >= 1 && dim <= 8192, "rr_index_create: dim %d out of [1, 8192]", dim);
+    RR_REQUIRE(dtype == RR_DTYPE_F32, "rr_index_create: dtype %d not built (fp32 only)", dtype);
+    RR_REQUIRE(row_offset >= 0 && row_offset + n_rows < (1ll << 32),
+               "rr_index_create: global rows must stay below 2^32");
+    int ndev = 0;
+    RR_HIP_TRY(hipGetDeviceCount(&ndev));
+    RR_REQUIRE(device >= 0 && device < ndev, "rr_index_create: device %d not in [0,%d)", device, ndev);
+    RR_HIP_TRY(hipSetDevice(device));
+
+    rr_index* ix = new rr_index();
+    ix->device = device;
+    ix->n_rows = n_rows;
+    ix->dim = dim;
+    ix->dim_pad = (int32_t)rr_round_up(dim, 64);
+    ix->dtype = dtype;
+    ix->row_offset = row_offset;
+    hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ix->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ix->ev1);
+    for (int i = 0; i < rr_index::kRing && e == hipSuccess; ++i) {
+        e = hipEventCreate(&ix->ring0[i]);
+        if (e == hipSuccess) e = hipEventCreate(&ix->ring1[i]);
+    }
+    if (e == hipSuccess) e = hipMalloc(&ix->d_q, sizeof(float) * (size_t)RR_MAX_BATCH * ix->dim_pad);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_rows_out, sizeof(int64_t) * (size_t)RR_MAX_BATCH * RR_MAX_POOL);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_scores_out, sizeof(float) * (size_t)RR_MAX_BATCH * RR_MAX_POOL);
+    if (e != hipSuccess) {
+        rr_set_error("rr_index_create: %s", hipGetErrorString(e));
+        rr_index_destroy(ix);
+        return RR_E_HIP;
+    }
+    if (h_matrix) {
+        int rc = rr_index_upload_rows(ix, 0, n_rows, h_matrix);
+        if (rc) { rr_index_destroy(ix); return rc; }
+    }
+    *out = ix;
+    return RR_OK;
+}
+
+static int rr_alloc_matrix(rr_index* ix) {
+    if (ix->d_matrix) return RR_OK;
+    const size_t bytes = (size_t)ix->n_rows * ix->dim_pad * rr_elem_size(ix->dtype);
+    hipError_t e = hipMalloc(&ix->d_matrix, bytes);
+    if (e != hipSuccess) {
+        rr_set_error("rr_index: hipMalloc of %zu matrix bytes failed: %s", bytes, hipGetErrorString(e));
+        return RR_E_NOMEM;
+    }
+    ix->owns_matrix = true;
+    if (ix->dim_pad != ix->dim) RR_HIP_TRY(hipMemsetAsync(ix->d_matrix, 0, bytes, ix->stream));
+    return RR_OK;
+}
+
+extern "C" int rr_index_upload_rows(rr_index* ix, int64_t first_row, int64_t n_rows, const void* h_rows) {
+    RR_REQUIRE(ix && h_rows, "rr_index_upload_rows: NULL argument");
+    RR_REQUIRE(first_row >= 0 && n_rows >= 0 && first_row + n_rows <= ix->n_rows,
+               "rr_index_upload_rows: rows [%lld,%lld) outside [0,%lld)", (long long)first_row,
+               (long long)(first_row + n_rows), (long long)ix->n_rows);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    RR_HIP_TRY(hipSetDevice(ix->device));
+    RR_REQUIRE(ix->owns_matrix || !ix->d_matrix, "rr_index_upload_rows: matrix is caller-owned");
+    int rc = rr_alloc_matrix(ix);
+    if (rc) return rc;
+    const size_t es = rr_elem_size(ix->dtype);
+    char* dst = (char*)ix->d_matrix + (size_t)first_row * ix->dim_pad * es;
+    if (n_rows)
+        RR_HIP_TRY(hipMemcpy2DAsync(dst, es * ix->dim_pad, h_rows, es * ix->dim, es * ix->dim, (size_t)n_rows,
+                                    hipMemcpyHostToDevice, ix->stream));
+    RR_HIP_TRY(hipStreamSynchronize(ix->stream));
+    return RR_OK;
+}
+
+extern "C" int rr_index_adopt_device(rr_index* ix, const void* d_matrix) {
+    RR_REQUIRE(ix && d_matrix, "rr_index_adopt_device: NULL argument");
+    RR_REQUIRE(((uintptr_t)d_matrix & 15) == 0, "rr_index_adopt_device: matrix must be 16-byte aligned");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    RR_HIP_TRY(hipSetDevice(ix->device));
+    if (ix->d_matrix && ix->owns_matrix) hipFree(ix->d_matrix);
+    ix->d_matrix = const_cast<void*>(d_matrix);
+    ix->owns_matrix = false;
+    return RR_OK;
+}
+
+extern "C" int rr_index_dim_padded(const rr_index* ix, int32_t* out) {
+    RR_REQUIRE(ix && out, "rr_index_dim_padded: NULL argument");
+    *out = ix->dim_pad;
+    return RR_OK;
+}
+
+extern "C" int rr_index_set_meta(rr_index* ix, const double* h_n_reviews, const double* h_avg_stars,
+                                 const double* h_log1p_n) {
+    RR_REQUIRE(ix && h_n_reviews && h_avg_stars && h_log1p_n, "rr_index_set_meta: NULL argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    RR_HIP_TRY(hipSetDevice(ix->device));
+    const size_t bytes = sizeof(double) * (size_t)ix->n_rows;
+    if (!ix->d_n_reviews) RR_HIP_TRY(hipMalloc((void**)&ix->d_n_reviews, bytes));
+    if (!ix->d_avg_stars) RR_HIP_TRY(hipMalloc((void**)&ix->d_avg_stars, bytes));
+    if (!ix->d_log1p_n) RR_HIP_TRY(hipMalloc((void**)&ix->d_log1p_n, bytes));
+    RR_HIP_TRY(hipMemcpy(ix->d_n_reviews, h_n_reviews, bytes, hipMemcpyHostToDevice));
+    RR_HIP_TRY(hipMemcpy(ix->d_avg_stars, h_avg_stars, bytes, hipMemcpyHostToDevice));
+    RR_HIP_TRY(hipMemcpy(ix->d_log1p_n, h_log1p_n, bytes, hipMemcpyHostToDevice));
+    ix->has_meta = true;
+    return RR_OK;
+}
+
+extern "C" int rr_index_destroy(rr_index* ix) {
+    if (!ix) return RR_OK;
+    hipSetDevice(ix->device);
+    if (ix->stream) hipStreamSynchronize(ix->stream);
+    if (ix->d_matrix && ix->owns_matrix) hipFree(ix->d_matrix);
+    hipFree(ix->d_n_reviews); hipFree(ix->d_avg_stars); hipFree(ix->d_log1p_n);
+    hipFree(ix->d_sims); hipFree(ix->d_gmax); hipFree(ix->d_q);
+    hipFree(ix->d_rows_out); hipFree(ix->d_scores_out);
+    if (ix->ev0) hipEventDestroy(ix->ev0);
+    if (ix->ev1) hipEventDestroy(ix->ev1);
+    for (int i = 0; i < rr_index::kRing; ++i) {
+        if (ix->ring0[i]) hipEventDestroy(ix->ring0[i]);
+        if (ix->ring1[i]) hipEventDestroy(ix->ring1[i]);
+    }
+    if (ix->stream) hipStreamDestroy(ix->stream);
+    delete ix;
+    return RR_OK;
+}
+
+extern "C" int rr_index_stream(rr_index* ix, void** out_stream) {
+    RR_REQUIRE(ix && out_stream, "rr_index_stream: NULL argument");
+    *out_stream = (void*)ix->stream;
+    return RR_OK;
+}
+
+extern "C" int rr_index_synchronize(rr_index* ix) {
+    RR_REQUIRE(ix, "rr_index_synchronize: NULL handle");
+    RR_HIP_TRY(hipSetDevice(ix->device));
+    RR_HIP_TRY(hipStreamSynchronize(ix->stream));
+    return RR_OK;
+}

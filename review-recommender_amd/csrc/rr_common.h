@@ -1,0 +1,123 @@
+// rr_common.h -- shared host/device helpers of librr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+
+#include "../../include/rr_hip.h"
+
+// ---------------------------------------------------------------- errors
+void rr_set_error(const char* fmt, ...);
+
+#define RR_HIP_TRY(expr)                                                        \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) {                                                 \
+            rr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                   \
+            return RR_E_HIP;                                                    \
+        }                                                                       \
+    } while (0)
+
+#define RR_REQUIRE(cond, ...)             \
+    do {                                  \
+        if (!(cond)) {                    \
+            rr_set_error(__VA_ARGS__);    \
+            return RR_E_INVALID;          \
+        }                                 \
+    } while (0)
+
+// ---------------------------------------------------------------- handles
+struct rr_index {
+    int device = 0;
+    int64_t n_rows = 0;
+    int32_t dim = 0;        // caller's dimension
+    int32_t dim_pad = 0;    // multiple of 64
+    int32_t dtype = RR_DTYPE_F32;
+    int64_t row_offset = 0;
+    void* d_matrix = nullptr;   // n_rows x dim_pad
+    bool owns_matrix = true;
+    double* d_n_reviews = nullptr;
+    double* d_avg_stars = nullptr;
+    double* d_log1p_n = nullptr;
+    bool has_meta = false;
+    // scratch for K1 (grown on demand)
+    float* d_sims = nullptr;     // [qcap][n_pad]
+    float* d_gmax = nullptr;     // [qcap][n_tiles]
+    int32_t scratch_q = 0;
+    float* d_q = nullptr;        // staged queries [RR_MAX_BATCH][dim_pad]
+    int64_t* d_rows_out = nullptr;  // host-API staging [RR_MAX_BATCH][RR_MAX_POOL]
+    float* d_scores_out = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // last scan
+    bool timing_valid = false;
+    static const int kRing = 512;               // event pairs around every scan launch
+    hipEvent_t ring0[kRing] = {}, ring1[kRing] = {};
+    int64_t ring_head = 0, ring_tail = 0;       // [tail, head) recorded, not yet drained
+    std::mutex mu;
+};
+
+struct rr_bm25 {
+    int device = 0;
+    int64_t n_docs = 0, n_terms = 0, nnz = 0;
+    int64_t row_offset = 0;
+    int64_t* d_post_indptr = nullptr;
+    int32_t* d_post_docs = nullptr;
+    int32_t* d_post_tf = nullptr;
+    int64_t* d_doc_indptr = nullptr;
+    int32_t* d_doc_terms = nullptr;
+    int32_t* d_doc_tf = nullptr;
+    int32_t* d_doc_len = nullptr;
+    double* d_idf = nullptr;
+    double avgdl = 1.0, k1 = 1.5, b = 0.75;
+    bool owns_arrays = true;
+    double* d_scores = nullptr;   // n_docs, scratch of get_scores
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+};
+
+static inline int64_t rr_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Order-preserving map float -> uint32 (a < b  <=>  key(a) < key(b)); NaN is
+// canonicalised by the callers before keys are taken.
+__device__ __forceinline__ uint32_t rr_f2key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float rr_key2f(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+
+// Sum over the 16 lanes of a DPP row; every lane of the row ends with the same
+// value.  Fixed association: ((p0+p1)+(p2+p3)) per quad, quads paired by
+// row_half_mirror, halves by row_mirror -- the order oracle/kernel_order.c mirrors.
+__device__ __forceinline__ float rr_row16_sum(float v) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v = v + __int_as_float(t);
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v = v + __int_as_float(t);
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v = v + __int_as_float(t);
+    t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true);  // row_mirror
+    v = v + __int_as_float(t);
+    return v;
+}
+
+__device__ __forceinline__ float rr_wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,377 @@
+"""The drop-in search engine: the reference's Python call boundary over the HIP kernels.
+
+Boundary kept:
+  cosine_similarity_search(query_vector, embeddings_matrix, top_k)   utils.py:111-124
+  run_search(query, k, rerank_k, w_dense, w_bm25, w_rerank, w_prior, w_best, prior_C,
+             use_snips, max_scan, min_reviews, gate_penalty)
+             -> (DataFrame, snips, dbg)                 app/app_product_search.py:245-317
+  search(query, k, alpha)                               north-star sugar over run_search
+  CLI flavour (pool floor 100, no trust factor)         app/test.py:228-342
+
+Per query batch the device does K1 (dense scan + exact top-pool), K2 (BM25 at the
+pool), K3 (min-max, priors, trust, blend, gate, top-k) back to back on one HIP stream;
+the host only tokenises, matches gate strings and builds the result frame.
+torch is used for device buffers and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import pandas as pd
+
+from . import _lib, text
+from .bm25 import BM25Corpus, BM25Index
+from .index import MAX_POOL, ProductIndex
+
+APP_POOL_FLOOR = 150    # app/app_product_search.py:253
+CLI_POOL_FLOOR = 100    # app/test.py:238
+APP_TRUST_SAT = 80      # app/app_product_search.py:303
+COLUMN_NAMES = ("_dense", "_bm25", "_prior", "_rerank", "_best", "_gate", "_trust", "_final")
+_FLOAT32_COLUMNS = {"_dense", "_bm25", "_best", "_gate", "_trust", "_final"}
+
+
+@dataclass
+class FusionWeights:
+    """run_search's scoring parameters (defaults: config.py:64-72, prior_C app/...:402)."""
+    w_dense: float = 0.55
+    w_bm25: float = 0.20
+    w_rerank: float = 0.20
+    w_prior: float = 0.20
+    w_best: float = 0.10
+    prior_C: float = 20.0
+    min_reviews: int = 8
+    gate_penalty: float = 0.5
+    trust_sat: int = APP_TRUST_SAT
+    apply_trust: bool = True
+
+
+@dataclass
+class BatchResult:
+    """Raw result of one query batch (numpy, host)."""
+    pool_rows: np.ndarray      # (B, pool) global rows in pool order (dense desc, row asc)
+    columns: np.ndarray        # (B, 8, pool) float64: COLUMN_NAMES
+    order: np.ndarray          # (B, k) pool positions of the top-k, best first
+    dense_raw: np.ndarray      # (B, pool) float32 raw cosine scores
+    bm25_raw: np.ndarray       # (B, pool) float32 raw BM25 scores
+    pool: int
+    k: int
+
+    def topk_rows(self) -> np.ndarray:
+        return np.take_along_axis(self.pool_rows, self.order.astype(np.int64), axis=1)
+
+    def topk_column(self, name: str) -> np.ndarray:
+        c = self.columns[:, COLUMN_NAMES.index(name), :]
+        return np.take_along_axis(c, self.order.astype(np.int64), axis=1)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class HybridSearcher:
+    """K1 -> K2 -> K3 on one GPU over a ProductIndex (+ optional BM25Index)."""
+
+    def __init__(self, index: ProductIndex, bm25: Optional[BM25Index] = None):
+        if not index.has_meta:
+            raise ValueError("the index needs metadata (ProductIndex.set_meta) before searching")
+        self.index, self.bm25 = index, bm25
+        self.lib = _lib.load()
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.HipLibraryError("no GPU visible: the search path runs on the device only")
+        self.device = torch.device("cuda", index.device)
+        self._term_cache = {}
+
+    # -------------------------------------------------------------- device steps
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def dense_pool(self, q_dev, pool: int):
+        """K1 on device tensors: (rows int64 (B,pool), scores float32 (B,pool))."""
+        torch = _torch()
+        B = q_dev.shape[0]
+        rows = torch.empty((B, pool), dtype=torch.int64, device=self.device)
+        dense = torch.empty((B, pool), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.rr_dense_topk_dev(self.index.handle, C.c_void_p(q_dev.data_ptr()), B, pool,
+                                              C.c_void_p(rows.data_ptr()), C.c_void_p(dense.data_ptr()),
+                                              self._stream()), "rr_dense_topk_dev")
+        return rows, dense
+
+    def bm25_at(self, term_id_lists: Sequence[Sequence[int]], rows_dev, mode: str = "forward"):
+        """K2 on device tensors: float32 (B, pool) raw BM25 at the candidate rows."""
+        torch = _torch()
+        B, pool = rows_dev.shape
+        out = torch.zeros((B, pool), dtype=torch.float32, device=self.device)
+        if self.bm25 is None or not any(len(t) for t in term_id_lists):
+            return out   # no index / no tokens -> zeros (app/app_product_search.py:202,204)
+        ids_dev, off_dev = self._stage_terms(term_id_lists)
+        _lib.check(self.lib.rr_bm25_scores_at_dev(
+            self.bm25.handle, C.c_void_p(ids_dev.data_ptr()), C.c_void_p(off_dev.data_ptr()), B,
+            C.c_void_p(rows_dev.data_ptr()), pool, {"forward": 0, "postings": 1}[mode],
+            C.c_void_p(out.data_ptr()), self._stream()), "rr_bm25_scores_at_dev")
+        return out
+
+    def _stage_terms(self, term_id_lists):
+        """Token ids of a batch as device arrays (flat ids + offsets).  A batch object that
+        is searched again (bench.py replays its query sets) is staged once."""
+        torch = _torch()
+        hit = self._term_cache.get(id(term_id_lists))
+        if hit is not None and hit[0] is term_id_lists:
+            return hit[1], hit[2]
+        B = len(term_id_lists)
+        off = np.zeros(B + 1, dtype=np.int32)
+        for i, t in enumerate(term_id_lists):
+            if len(t) > 64:
+                raise ValueError("a query may carry at most 64 tokens (RR_MAX_QTERMS)")
+            off[i + 1] = off[i] + len(t)
+        flat = np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in term_id_lists])
+        ids_dev = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.int32)).to(self.device)
+        off_dev = torch.from_numpy(off).to(self.device)
+        if len(self._term_cache) >= 64:
+            self._term_cache.clear()
+        self._term_cache[id(term_id_lists)] = (term_id_lists, ids_dev, off_dev)
+        return ids_dev, off_dev
+
+    def fuse(self, params: "_lib.FuseParams", B: int, rows, dense, bm25, meta=None,
+             rerank=None, best=None, gate=None):
+        """K3 on device tensors -> (out_rows (B,pool), cols (B,8,pool) f64, order (B,k))."""
+        torch = _torch()
+        pool, k = params.pool, params.k
+        out_rows = torch.empty((B, pool), dtype=torch.int64, device=self.device)
+        cols = torch.empty((B, 8, pool), dtype=torch.float64, device=self.device)
+        order = torch.empty((B, k), dtype=torch.int32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        n, avg, l1p = meta if meta is not None else (None, None, None)
+        _lib.check(self.lib.rr_fuse_topk_dev(
+            self.index.handle, C.byref(params), B, p(rows), p(dense), p(bm25), p(n), p(avg), p(l1p),
+            p(rerank), p(best), p(gate), p(out_rows), p(cols), p(order), self._stream()),
+            "rr_fuse_topk_dev")
+        return out_rows, cols, order
+
+    # -------------------------------------------------------------- one batch
+    @staticmethod
+    def make_params(w: FusionWeights, k: int, pool: int, n_candidates: int, rerank_k: int,
+                    cand_per_rank: int = 0, stride_bytes: int = 0) -> "_lib.FuseParams":
+        return _lib.FuseParams(
+            w_dense=w.w_dense, w_bm25=w.w_bm25, w_rerank=w.w_rerank, w_prior=w.w_prior,
+            w_best=w.w_best, prior_C=w.prior_C, min_reviews=int(w.min_reviews),
+            trust_sat=int(w.trust_sat), apply_trust=int(bool(w.apply_trust)),
+            rerank_active=int(rerank_k > 0), rerank_k=int(rerank_k), k=int(k),
+            n_candidates=int(n_candidates), pool=int(pool), cand_per_rank=int(cand_per_rank),
+            _pad=0, cand_rank_stride_bytes=int(stride_bytes))
+
+    def search_batch(self, qvecs: np.ndarray, term_id_lists: Optional[Sequence[Sequence[int]]],
+                     k: int, rerank_k: int = 0, weights: Optional[FusionWeights] = None,
+                     pool_floor: int = APP_POOL_FLOOR,
+                     gate_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+                     rerank_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+                     bm25_mode: str = "forward") -> BatchResult:
+        """qvecs (B, dim) float32; term_id_lists: per-query BM25 token ids (None = no BM25).
+        gate_fn / rerank_fn map the (B, pool) pool rows to (B, pool) float32 gate factors /
+        (B, rr_k) raw reranker scores; they run on the host between K2 and K3."""
+        torch = _torch()
+        w = weights or FusionWeights()
+        q = np.ascontiguousarray(qvecs, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.index.dim:
+            raise ValueError(f"qvecs must be (B, {self.index.dim}); got {q.shape}")
+        B = q.shape[0]
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        pool = min(max(k, rerank_k, pool_floor), self.index.n_rows)
+        if pool > MAX_POOL:
+            raise ValueError(f"pool {pool} exceeds the kernels' limit {MAX_POOL}")
+        k_eff = min(k, pool)
+        rr_k = min(rerank_k, pool)
+        with torch.cuda.device(self.device):
+            q_dev = torch.from_numpy(q).to(self.device)
+            rows, dense = self.dense_pool(q_dev, pool)
+            tl = term_id_lists if term_id_lists is not None else [[] for _ in range(B)]
+            bm = self.bm25_at(tl, rows, bm25_mode)
+            gate = rerank = None
+            if gate_fn is not None or (rerank_fn is not None and rr_k > 0):
+                rows_h = rows.cpu().numpy()
+                if gate_fn is not None:
+                    g = np.ascontiguousarray(gate_fn(rows_h), dtype=np.float32)
+                    gate = torch.from_numpy(g).to(self.device)
+                if rerank_fn is not None and rr_k > 0:
+                    r = np.zeros((B, pool), dtype=np.float32)
+                    r[:, :rr_k] = np.asarray(rerank_fn(rows_h[:, :rr_k]), dtype=np.float32)
+                    rerank = torch.from_numpy(r).to(self.device)
+            params = self.make_params(w, k_eff, pool, pool, rr_k)
+            out_rows, cols, order = self.fuse(params, B, rows, dense, bm, None, rerank, None, gate)
+            res = BatchResult(out_rows.cpu().numpy(), cols.cpu().numpy(), order.cpu().numpy(),
+                              dense.cpu().numpy(), bm.cpu().numpy(), pool, k_eff)
+        return res
+
+
+class SearchEngine:
+    """The reference's search API over one GPU.
+
+    meta: DataFrame with ``sku, n_reviews, avg_stars, agg_text`` (+ any other column),
+    row-aligned with ``embeddings`` (product_emb_meta.parquet / product_emb.npy).
+    bm25_blob: the ``{"skus", "corpus"}`` dict of product_bm25.pkl, or None.
+    encoder: object with ``encode([query], normalize_embeddings=True)`` (SentenceTransformer API).
+    cross_encoder: object with ``predict(pairs, batch_size=64, show_progress_bar=False)``.
+    """
+
+    def __init__(self, meta: pd.DataFrame, embeddings: np.ndarray, bm25_blob: Optional[dict] = None,
+                 *, encoder=None, cross_encoder=None, device: int = 0, normalize: bool = True,
+                 flavour: str = "app"):
+        if flavour not in ("app", "cli"):
+            raise ValueError("flavour must be 'app' or 'cli'")
+        if len(meta) != embeddings.shape[0]:
+            # app/app_product_search.py:104-107, app/test.py:141-142: hard error
+            raise ValueError(f"metadata has {len(meta)} rows but embeddings have "
+                             f"{embeddings.shape[0]} rows")
+        if "sku" not in meta.columns or "agg_text" not in meta.columns:
+            raise ValueError("metadata must have 'sku' and 'agg_text' columns")  # app/test.py:138-139
+        self.flavour = flavour
+        self.meta = meta.reset_index(drop=True)
+        self.encoder, self.cross_encoder = encoder, cross_encoder
+        self.index = ProductIndex(embeddings, device=device, normalize=normalize)
+        nan = pd.Series([np.nan] * len(self.meta))
+        n = pd.to_numeric(self.meta.get("n_reviews", nan), errors="coerce").fillna(0).values
+        r = pd.to_numeric(self.meta.get("avg_stars", nan), errors="coerce").values
+        self.index.set_meta(n, r)
+        self._texts = self.meta["agg_text"].astype(str)
+        self.bm25_corpus: Optional[BM25Corpus] = None
+        bm25_index = None
+        if bm25_blob:
+            self.bm25_corpus = BM25Corpus.from_corpus(bm25_blob["corpus"])
+            aligned = self.bm25_corpus.select(self._align_bm25([str(s) for s in bm25_blob["skus"]]))
+            bm25_index = aligned.to_device(device)
+        self.searcher = HybridSearcher(self.index, bm25_index)
+
+    # app: sku -> last position, missing -> 0.0 score (app/app_product_search.py:207-208)
+    # cli: same map, but if ANY meta sku is missing the scores are used unpermuted
+    #      (ensure_same_order returns None, app/test.py:159-173)
+    def _align_bm25(self, bm25_skus: List[str]) -> np.ndarray:
+        pos = {s: i for i, s in enumerate(bm25_skus)}
+        meta_skus = self.meta["sku"].astype(str).tolist()
+        order = np.array([pos.get(s, -1) for s in meta_skus], dtype=np.int64)
+        if self.flavour == "cli" and (order < 0).any():
+            if len(bm25_skus) < len(meta_skus):
+                raise IndexError("BM25 corpus is shorter than the metadata and cannot be used unpermuted")
+            order = np.arange(len(meta_skus), dtype=np.int64)
+        return order
+
+    # ------------------------------------------------------------------ pieces
+    def encode(self, query: str) -> np.ndarray:
+        if self.encoder is None:
+            raise ValueError("no query encoder was given; use search_by_vector / pass qvec")
+        return np.asarray(self.encoder.encode([query], normalize_embeddings=True)[0], dtype=np.float32)
+
+    def _gate_fn(self, query: str, penalty: float):
+        groups = text.build_gate_groups(query)
+
+        def fn(rows: np.ndarray) -> np.ndarray:
+            out = np.ones(rows.shape, dtype=np.float32)
+            if not groups:
+                return out
+            for b in range(rows.shape[0]):
+                texts = self._texts.iloc[rows[b]].str.slice(0, 6000).tolist()
+                out[b] = np.array([text.calculate_gate_factor(t, groups, penalty)[0] for t in texts],
+                                  dtype=np.float32)
+            return out
+        return groups, fn
+
+    def _rerank_fn(self, query: str):
+        if self.cross_encoder is None:
+            return None   # model missing -> zeros (app/app_product_search.py:275)
+
+        def fn(rows: np.ndarray) -> np.ndarray:
+            out = np.zeros(rows.shape, dtype=np.float32)
+            for b in range(rows.shape[0]):
+                texts = self._texts.iloc[rows[b]].str.slice(0, 2000).tolist()
+                pairs = [(query, t) for t in texts]
+                out[b] = np.array(self.cross_encoder.predict(pairs, batch_size=64,
+                                                             show_progress_bar=False), dtype=np.float32)
+            return out
+        return fn
+
+    # ------------------------------------------------------------------ API
+    def run_search(self, query: str, k: int, rerank_k: int, w_dense: float, w_bm25: float,
+                   w_rerank: float, w_prior: float, w_best: float, prior_C: float,
+                   use_snips: bool = False, max_scan: int = 0, min_reviews: int = 8,
+                   gate_penalty: float = 0.5, *, qvec: Optional[np.ndarray] = None
+                   ) -> Tuple[pd.DataFrame, Dict, Dict]:
+        """Same positional / keyword signature and return triple as the reference's
+        run_search (app/app_product_search.py:245-248, 312-317); ``qvec`` lets a caller
+        supply the query embedding when no encoder is loaded.  Snippets (use_snips) are
+        outside the hot-path contract: ``snips`` is {} and ``_best`` is zeros."""
+        app = self.flavour == "app"
+        qv = self.encode(query) if qvec is None else np.asarray(qvec, dtype=np.float32)
+        toks = text.tokenize_query(query)
+        term_ids = None
+        if self.searcher.bm25 is not None:
+            term_ids = [self.searcher.bm25.term_ids(toks)]
+        groups, gate_fn = self._gate_fn(query, gate_penalty)
+        w = FusionWeights(w_dense, w_bm25, w_rerank, w_prior, w_best, prior_C, min_reviews,
+                          gate_penalty, APP_TRUST_SAT, app)
+        res = self.searcher.search_batch(
+            qv[None, :], term_ids, k, rerank_k, w,
+            pool_floor=APP_POOL_FLOOR if app else CLI_POOL_FLOOR,
+            gate_fn=gate_fn if groups else None,
+            rerank_fn=self._rerank_fn(query) if rerank_k > 0 else None)
+        frame = self._frame(res, 0)
+        dbg = {"bm25_active": self.searcher.bm25 is not None, "tokens": toks,
+               "groups": [list(g) for g in groups], "pool": max(k, rerank_k,
+                                                              APP_POOL_FLOOR if app else CLI_POOL_FLOOR)}
+        return frame, {}, dbg
+
+    def _frame(self, res: BatchResult, b: int) -> pd.DataFrame:
+        top = res.order[b].astype(np.int64)
+        out = self.meta.iloc[res.pool_rows[b][top]].reset_index(drop=True).copy()
+        for j, name in enumerate(COLUMN_NAMES):
+            col = res.columns[b, j, top]
+            if name == "_trust" and self.flavour == "cli":
+                continue   # the CLI has no trust column (app/test.py:308)
+            out[name] = col.astype(np.float32) if name in _FLOAT32_COLUMNS else col
+        return out
+
+    def search(self, query: str, k: int = 10, alpha: float = 0.5, *,
+               qvec: Optional[np.ndarray] = None) -> Tuple[pd.DataFrame, Dict, Dict]:
+        """search(query, k, alpha) of BASELINE.json: dense weight alpha, BM25 weight
+        1 - alpha, no rerank / prior / best, gate off."""
+        return self.run_search(query, k, 0, alpha, 1.0 - alpha, 0.0, 0.0, 0.0, 20.0, False, 0,
+                               8, 1.0, qvec=qvec)
+
+    def search_by_vector(self, qvec: np.ndarray, query: str = "", k: int = 10, alpha: float = 0.5):
+        return self.search(query, k, alpha, qvec=qvec)
+
+    def cosine_similarity_search(self, query_vector: np.ndarray, top_k: int):
+        rows, scores = self.index.dense_topk(np.asarray(query_vector, dtype=np.float32)[None, :], top_k)
+        return rows[0], scores[0]
+
+
+def cosine_similarity_search(query_vector: np.ndarray, embeddings_matrix: np.ndarray,
+                             top_k: int, device: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """utils.py:111-124 with the matrix copied to the GPU for this call; use
+    ProductIndex / SearchEngine to keep it resident across calls."""
+    ix = ProductIndex(np.asarray(embeddings_matrix, dtype=np.float32), device=device)
+    try:
+        rows, scores = ix.dense_topk(np.asarray(query_vector, dtype=np.float32)[None, :], top_k)
+    finally:
+        ix.close()
+    return rows[0], scores[0]
+
+
+def cli_rows(frame: pd.DataFrame) -> List[Dict]:
+    """The CLI's JSON row schema (app/test.py:312-328), 4-dp rounding."""
+    rows = []
+    for _, r in frame.iterrows():
+        n = r.get("n_reviews", np.nan)
+        a = r.get("avg_stars", np.nan)
+        rows.append({
+            "sku": str(r["sku"]), "score": round(float(r["_final"]), 4),
+            "dense": round(float(r["_dense"]), 4), "bm25": round(float(r["_bm25"]), 4),
+            "rerank": round(float(r["_rerank"]), 4), "prior": round(float(r["_prior"]), 4),
+            "bestrev": round(float(r["_best"]), 4),
+            "n_reviews": int(n) if pd.notna(n) else 0,
+            "avg_stars": round(float(a), 2) if pd.notna(a) else None,
+            "snippet_stars": None, "snippet": None})
+    return rows

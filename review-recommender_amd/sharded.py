@@ -1,0 +1,152 @@
+"""Row-sharded search over the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  Rank r owns a
+contiguous row range of the matrix, of n_reviews / avg_stars, and of the BM25 documents;
+idf / avgdl are corpus-wide and replicated.  Per query batch every rank runs K1 and K2 on
+its shard, packs the candidate payload
+
+    rows int64 | n_reviews f64 | avg_stars f64 | log1p_n f64 | dense f32 | bm25 f32     (40 B/candidate)
+
+into ONE contiguous device buffer, and a single all-gather moves all ranks' buffers to all
+ranks.  K3 then reads the gathered blocks in place ([rank][query][pool] addressing),
+merges world x pool candidates to the global top-pool by (dense desc, row asc) and fuses.
+Every rank ends with the same result.  The global top-pool is contained in the union of
+the local top-pools, and a row's score does not depend on the shard it sits in
+(csrc/rr_dense.hip), so the answer equals the single-GPU answer bit for bit.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .engine import FusionWeights, HybridSearcher
+
+
+def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row range of ``rank``: the first n_rows % world ranks get one extra row."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside [0, world)")
+    base, extra = divmod(n_rows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+@dataclass(frozen=True)
+class PayloadLayout:
+    """Byte offsets of the candidate payload one rank contributes (all 16-B aligned)."""
+    n_queries: int
+    pool: int
+
+    @property
+    def count(self) -> int:
+        return self.n_queries * self.pool
+
+    def _al(self, x: int) -> int:
+        return (x + 15) // 16 * 16
+
+    @property
+    def off_rows(self) -> int: return 0
+    @property
+    def off_n(self) -> int: return self._al(self.count * 8)
+    @property
+    def off_avg(self) -> int: return self.off_n + self._al(self.count * 8)
+    @property
+    def off_l1p(self) -> int: return self.off_avg + self._al(self.count * 8)
+    @property
+    def off_dense(self) -> int: return self.off_l1p + self._al(self.count * 8)
+    @property
+    def off_bm25(self) -> int: return self.off_dense + self._al(self.count * 4)
+    @property
+    def nbytes(self) -> int: return self.off_bm25 + self._al(self.count * 4)
+
+    def views(self, buf):
+        """Typed (n_queries, pool) views into one rank's uint8 buffer (torch tensor)."""
+        import torch
+        c, shape = self.count, (self.n_queries, self.pool)
+        v = lambda off, n, dt: buf[off:off + n].view(dt).view(shape)
+        return {"rows": v(self.off_rows, c * 8, torch.int64), "n": v(self.off_n, c * 8, torch.float64),
+                "avg": v(self.off_avg, c * 8, torch.float64), "l1p": v(self.off_l1p, c * 8, torch.float64),
+                "dense": v(self.off_dense, c * 4, torch.float32), "bm25": v(self.off_bm25, c * 4, torch.float32)}
+
+
+def exchange(buf, world: int, group=None):
+    """The path's one collective: all-gather of every rank's payload buffer.
+    Returns a (world, nbytes) uint8 tensor, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    out = torch.empty((world, buf.numel()), dtype=torch.uint8, device=buf.device)
+    if world == 1:
+        out[0].copy_(buf)
+        return out
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, buf, group=group)       # RCCL over xGMI
+    else:                                                         # gloo (CPU tests)
+        parts = [out[r] for r in range(world)]
+        dist.all_gather(parts, buf, group=group)
+    return out
+
+
+class ShardedSearcher:
+    """K1 + K2 per shard, one all-gather, K3 on the merged pool."""
+
+    def __init__(self, searcher: HybridSearcher, n_total_rows: int, rank: int, world: int, group=None):
+        lo, hi = shard_bounds(n_total_rows, world, rank)
+        ix = searcher.index
+        if ix.row_offset != lo or ix.n_rows != hi - lo:
+            raise ValueError(f"rank {rank} must hold rows [{lo}, {hi}); its index holds "
+                             f"[{ix.row_offset}, {ix.row_offset + ix.n_rows})")
+        self.s, self.rank, self.world, self.group, self.n_total = searcher, rank, world, group, n_total_rows
+
+    def local_payload(self, q_dev, term_id_lists, pool_local: int, bm25_mode: str = "forward"):
+        """K1 + K2 + metadata gather into the payload buffer of this rank."""
+        import torch
+        s = self.s
+        B = q_dev.shape[0]
+        lay = PayloadLayout(B, pool_local)
+        buf = torch.empty(lay.nbytes, dtype=torch.uint8, device=s.device)
+        v = lay.views(buf)
+        rows, dense = s.dense_pool(q_dev, pool_local)
+        bm = s.bm25_at(term_id_lists, rows, bm25_mode)
+        v["rows"].copy_(rows)
+        v["dense"].copy_(dense)
+        v["bm25"].copy_(bm)
+        _lib.check(s.lib.rr_index_gather_meta_dev(
+            s.index.handle, C.c_void_p(v["rows"].data_ptr()), B * pool_local,
+            C.c_void_p(v["n"].data_ptr()), C.c_void_p(v["avg"].data_ptr()),
+            C.c_void_p(v["l1p"].data_ptr()), s._stream()), "rr_index_gather_meta_dev")
+        return lay, buf
+
+    def search_batch_dev(self, q_dev, term_id_lists: Optional[Sequence[Sequence[int]]], k: int,
+                         weights: Optional[FusionWeights] = None, pool_floor: int = 150,
+                         bm25_mode: str = "forward"):
+        """Device-resident queries in, device tensors out: (pool_rows, columns, order)."""
+        import torch
+        w = weights or FusionWeights()
+        B = q_dev.shape[0]
+        pool = min(max(k, pool_floor), self.n_total)
+        pool_local = min(pool, self.s.index.n_rows)
+        if self.world > 1:
+            # every rank must contribute the same count for the strided addressing
+            assert pool_local == pool, "each shard needs at least `pool` rows"
+        tl = term_id_lists if term_id_lists is not None else [[] for _ in range(B)]
+        lay, buf = self.local_payload(q_dev, tl, pool_local, bm25_mode)
+        gathered = exchange(buf, self.world, self.group)
+        base = gathered.data_ptr()
+        ptr = lambda off: C.c_void_p(base + off)
+        params = HybridSearcher.make_params(w, min(k, pool), pool, self.world * pool_local, 0,
+                                            cand_per_rank=pool_local, stride_bytes=lay.nbytes)
+        s = self.s
+        out_rows = torch.empty((B, pool), dtype=torch.int64, device=s.device)
+        cols = torch.empty((B, 8, pool), dtype=torch.float64, device=s.device)
+        order = torch.empty((B, params.k), dtype=torch.int32, device=s.device)
+        _lib.check(s.lib.rr_fuse_topk_dev(
+            s.index.handle, C.byref(params), B, ptr(lay.off_rows), ptr(lay.off_dense), ptr(lay.off_bm25),
+            ptr(lay.off_n), ptr(lay.off_avg), ptr(lay.off_l1p), None, None, None,
+            C.c_void_p(out_rows.data_ptr()), C.c_void_p(cols.data_ptr()), C.c_void_p(order.data_ptr()),
+            s._stream()), "rr_fuse_topk_dev")
+        self._keep = (gathered, buf)   # alive until the stream has consumed them
+        return out_rows, cols, order

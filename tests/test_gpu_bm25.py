@@ -1,0 +1,83 @@
+"""K2 parity on the GPU through the C ABI (rr_bm25_*): bit-exact float64 against the
+oracle's restatement of rank_bm25 (BM25 parity itself is unpinned, oracle/bm25.py)."""
+import numpy as np
+import pytest
+
+from oracle.bm25 import BM25CsrOracle, BM25OkapiOracle
+from review_recommender_amd import synth
+from review_recommender_amd.bm25 import BM25Corpus, BM25Okapi
+
+pytestmark = pytest.mark.gpu
+
+CORPUS = [["wireless", "headphones", "bluetooth"],
+          ["yellow", "cat", "socks", "soft"],
+          ["gaming", "keyboard", "mechanical"]]
+
+
+def csr_oracle(c: BM25Corpus) -> BM25CsrOracle:
+    order = np.argsort(c.doc_terms, kind="stable")
+    docs = np.repeat(np.arange(c.n_docs), np.diff(c.doc_indptr))[order]
+    indptr = np.concatenate([[0], np.cumsum(np.bincount(c.doc_terms, minlength=c.n_terms))])
+    return BM25CsrOracle(indptr, docs, c.doc_tf[order], c.doc_len, c.idf, c.avgdl, c.k1, c.b)
+
+
+def test_drop_in_class_on_the_reference_fixture_corpus():
+    gpu = BM25Okapi(CORPUS)
+    ora = BM25OkapiOracle(CORPUS)
+    assert gpu.corpus_size == 3 and gpu.avgdl == ora.avgdl and gpu.idf == ora.idf
+    for q in (["wireless", "headphones"], ["cat", "cat", "zebra"], [], ["mechanical", "soft"]):
+        s = gpu.get_scores(q)
+        assert s.dtype == np.float64 and np.array_equal(s, ora.get_scores(q))
+
+
+def test_string_corpus_get_scores_and_candidate_scores_bit_exact():
+    corpus = [t.split() for t in synth.text_corpus(5000, 3, mean_len=30)]
+    gpu = BM25Okapi(corpus)
+    ora = BM25OkapiOracle(corpus)
+    rng = np.random.default_rng(0)
+    for q in (["wireless", "cat", "usb"], ["dog"] * 5 + ["nothing"], ["blue", "red", "green", "black", "white"]):
+        full = ora.get_scores(q)
+        assert np.array_equal(gpu.get_scores(q), full)
+        rows = rng.choice(5000, size=(1, 150), replace=False).astype(np.int64)
+        want = np.array(full, dtype=np.float32)[rows]            # app/app_product_search.py:206-208
+        for mode in ("forward", "postings"):
+            got = gpu.index.scores_at_ids([gpu.index.term_ids(q)], rows, mode)
+            assert got.dtype == np.float32 and np.array_equal(got, want)
+
+
+def test_integer_corpus_100k_docs_batched():
+    ip, terms, tf, dl = synth.bm25_forward_csr(100_000, 20_000, 40, 17)
+    host = BM25Corpus(ip, terms, tf, dl, 20_000)
+    dev = host.to_device()
+    ora = csr_oracle(host)
+    df = np.bincount(terms, minlength=20_000)
+    queries = synth.query_terms(16, 20_000, 5, df)
+    queries[3] = np.array([0, 0, -1, 1], dtype=np.int32)            # head terms, duplicate, unknown
+    rng = np.random.default_rng(1)
+    rows = rng.integers(0, 100_000, size=(16, 150)).astype(np.int64)
+    full = [ora.get_scores(q) for q in queries]
+    assert np.array_equal(dev.get_scores_ids(queries[3]), full[3])
+    assert np.array_equal(dev.get_scores_ids(queries[0]), full[0])
+    want = np.stack([np.array(f, dtype=np.float32)[r] for f, r in zip(full, rows)])
+    for mode in ("forward", "postings"):
+        assert np.array_equal(dev.scores_at_ids(queries, rows, mode), want)
+
+
+def test_shard_scores_with_corpus_wide_statistics():
+    ip, terms, tf, dl = synth.bm25_forward_csr(10_000, 3000, 40, 23)
+    host = BM25Corpus(ip, terms, tf, dl, 3000)
+    ora = csr_oracle(host)
+    q = synth.query_terms(1, 3000, 9, np.bincount(terms, minlength=3000))
+    full = np.array(ora.get_scores(q[0]), dtype=np.float32)
+    rows = np.arange(4000, 4150, dtype=np.int64)[None, :]
+    shard = host.slice(3000, 7000).to_device(row_offset=3000)
+    assert np.array_equal(shard.scores_at_ids(q, rows), full[rows])
+    outside = np.array([[10, 2999, 7000, 9999]], dtype=np.int64)       # not in this shard -> 0
+    assert np.array_equal(shard.scores_at_ids(q, outside), np.zeros((1, 4), np.float32))
+    assert np.array_equal(shard.get_scores_ids(q[0]), ora.get_scores(q[0])[3000:7000])
+
+
+def test_too_many_query_tokens_is_an_error():
+    dev = BM25Corpus.from_corpus(CORPUS).to_device()
+    with pytest.raises(ValueError):
+        dev.scores_at_ids([np.zeros(65, dtype=np.int32)], np.zeros((1, 3), dtype=np.int64))

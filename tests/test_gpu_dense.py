@@ -1,0 +1,170 @@
+"""K1 parity on the GPU, through the C ABI (rr_dense_topk / rr_index_*): the HIP scan +
+selection against the oracle (numpy restatement of utils.py:111-124) and the golden
+vectors the reference's own utils.py produced."""
+import numpy as np
+import pytest
+
+from oracle import dense as OD
+from parity import assert_topk_matches, min_gap
+from review_recommender_amd import synth
+from review_recommender_amd.engine import cosine_similarity_search
+from review_recommender_amd.index import ProductIndex
+
+pytestmark = pytest.mark.gpu
+
+
+def check_against_oracle(V, Q, pool, index=None):
+    ix = index or ProductIndex(V)
+    rows, scores = ix.dense_topk(Q, pool)
+    eff = min(pool, V.shape[0])
+    assert rows.shape == (len(Q), eff) and rows.dtype == np.int64 and scores.dtype == np.float32
+    for i, q in enumerate(Q):
+        ref64 = OD.sims_float64(V, q)
+        assert_topk_matches(rows[i], scores[i], ref64, eff)
+        # and against the reference-order oracle wherever its top-k has clear gaps
+        o_rows, o_sims = OD.cosine_similarity_search(q, V, pool)
+        if min_gap(ref64, eff) > 1e-6:
+            assert np.array_equal(rows[i], o_rows), "IDs must be bit-exact"
+        np.testing.assert_allclose(scores[i], o_sims[:eff] if len(o_sims) else o_sims, atol=1e-5, rtol=0)
+    if index is None:
+        ix.close()
+    return rows, scores
+
+
+def test_reference_toy_cases():
+    # tests/test_utils.py:181-208 of the reference
+    emb = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]], dtype=np.float32)
+    q = np.array([0.0, 1.0], dtype=np.float32)
+    rows, sims = cosine_similarity_search(q, emb, 2)
+    assert len(rows) == 2 and rows[0] == 1 and sims[0] == 1.0 and rows.dtype == np.int64
+    rows, sims = cosine_similarity_search(q, emb[:2], 10)        # top_k > N returns N
+    assert len(rows) == 2 and len(sims) == 2
+    rows, sims = cosine_similarity_search(q, emb, 0)             # top_k == 0 -> empty
+    assert len(rows) == 0 and len(sims) == 0
+
+
+def test_golden_10k_from_reference_utils(golden_dense):
+    n, dim, seed_v, seed_q, k = golden_dense["recipe"].tolist()
+    V = synth.unit_rows(n, dim, seed_v)
+    Q = synth.unit_rows(golden_dense["rows"].shape[0], dim, seed_q)
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(Q, k)
+    for i in range(len(Q)):
+        ref64 = OD.sims_float64(V, Q[i])
+        assert min_gap(ref64, k) > 1e-6            # the recipe has no near-ties: IDs must be exact
+        assert np.array_equal(rows[i], golden_dense["rows"][i])
+        np.testing.assert_allclose(scores[i], golden_dense["sims"][i], atol=1e-5, rtol=0)
+    ix.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 150, 151, 1000, 4097, 20000])
+@pytest.mark.parametrize("pool", [1, 10, 150])
+def test_ragged_row_counts(n, pool):
+    V = synth.unit_rows(n, 384, 100 + n)
+    Q = synth.unit_rows(2, 384, 7)
+    check_against_oracle(V, Q, pool)
+
+
+@pytest.mark.parametrize("dim", [2, 3, 64, 100, 128, 384, 768, 1000])
+def test_other_dimensions(dim):
+    V = synth.unit_rows(3000, dim, dim)
+    Q = synth.unit_rows(3, dim, dim + 1)
+    check_against_oracle(V, Q, 100)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 4, 5, 8, 9, 17, 64])
+def test_batches_and_batch_invariance(batch):
+    V = synth.unit_rows(30000, 384, 11)
+    Q = synth.unit_rows(batch, 384, 12)
+    ix = ProductIndex(V)
+    rows, scores = check_against_oracle(V, Q, 150, ix)
+    # a query's answer does not depend on the batch it travels in: bitwise equal
+    r1, s1 = ix.dense_topk(Q[-1:], 150)
+    assert np.array_equal(r1[0], rows[-1]) and np.array_equal(s1[0], scores[-1])
+    ix.close()
+
+
+def test_exact_ties_resolve_to_the_smaller_row():
+    V = synth.unit_rows(5000, 384, 21)
+    V[100:4000:100] = V[7]                      # 39 exact copies of row 7
+    q = V[7].copy()
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(q[None, :], 50)
+    dup = [7] + list(range(100, 4000, 100))
+    assert rows[0][:40].tolist() == sorted(dup)           # equal scores -> ascending row
+    assert np.all(scores[0][:40] == scores[0][0])
+    ix.close()
+
+
+def test_massive_ties_all_rows_equal():
+    V = np.tile(synth.unit_rows(1, 384, 5), (300000, 1))   # every tile maximum ties (> 4096 tiles)
+    q = synth.unit_rows(1, 384, 6)
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(q, 150)
+    assert rows[0].tolist() == list(range(150)) and np.all(scores[0] == scores[0][0])
+    z = np.zeros((9000, 384), dtype=np.float32)
+    ixz = ProductIndex(z)
+    rows, scores = ixz.dense_topk(q, 2048)
+    assert rows[0].tolist() == list(range(2048)) and np.all(scores[0] == 0)
+    ix.close(); ixz.close()
+
+
+def test_clustered_rows_take_the_radix_fallback():
+    # rows sorted by score: the best pool tiles hold > 8192 qualifying rows
+    V = synth.unit_rows(60000, 384, 31)
+    q = synth.unit_rows(1, 384, 32)
+    order = np.argsort(-(V.astype(np.float64) @ q[0].astype(np.float64)))
+    Vs = np.ascontiguousarray(V[order])
+    rows, _ = check_against_oracle(Vs, q, 150)
+    assert rows[0].tolist() == list(range(150))
+
+
+def test_nan_rows_rank_last_and_results_stay_deterministic():
+    V = synth.unit_rows(2000, 384, 41)
+    V[5, 3] = np.nan
+    q = synth.unit_rows(1, 384, 42)
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(q, 1999)
+    assert 5 not in rows[0].tolist()
+    ix.close()
+
+
+def test_argument_errors_are_raised_not_swallowed():
+    V = synth.unit_rows(100, 384, 1)
+    ix = ProductIndex(V)
+    with pytest.raises(ValueError):
+        ix.dense_topk(np.zeros((1, 383), dtype=np.float32), 10)
+    with pytest.raises(ValueError):
+        ix.dense_topk(np.zeros((1, 384), dtype=np.float32), -1)
+    ix.close()
+
+
+def test_l2_normalize_on_device_matches_numpy_to_rounding():
+    from oracle.primitives import l2_normalize
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((1000, 384)).astype(np.float32) * 3
+    X[10] = 0
+    ix = ProductIndex(X, normalize=True)
+    q = synth.unit_rows(1, 384, 9)
+    rows, scores = ix.dense_topk(q, 100)
+    ref = OD.sims_float64(l2_normalize(X), q[0])
+    assert_topk_matches(rows[0], scores[0], ref, 100, tie_eps=1e-6)
+    ix.close()
+
+
+def test_one_million_rows_full_size():
+    """BASELINE config 2 size (1M x 384 fp32): checked against a chunked float64 oracle."""
+    n = 1_000_000
+    V = synth.unit_rows(n, 384, 1234)
+    Q = synth.unit_rows(2, 384, 77)
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(Q, 150)
+    for i in range(2):
+        ref = np.concatenate([V[s:s + 100000].astype(np.float64) @ Q[i].astype(np.float64)
+                              for s in range(0, n, 100000)])
+        assert_topk_matches(rows[i], scores[i], ref, 150)
+        o_rows, o_sims = OD.cosine_similarity_search(Q[i], V, 150)
+        if min_gap(ref, 150) > 1e-6:
+            assert np.array_equal(rows[i], o_rows)
+    assert ix.last_scan_ms() > 0
+    ix.close()
