@@ -82,7 +82,8 @@ int rr_index_destroy(rr_index* ix);
 int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_queries, int32_t pool,
                   int64_t* h_out_rows, float* h_out_scores, int32_t* pool_out);
 /* Same with device-resident queries and outputs, asynchronous on `stream`
- * (a hipStream_t passed as void*; NULL = the handle's own stream). */
+ * (a hipStream_t passed as void*; NULL = the device's default stream, which is what
+ * torch.cuda.current_stream().cuda_stream is unless the caller switched streams). */
 int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t pool,
                       int64_t* d_out_rows, float* d_out_scores, void* stream);
 /* Timing of the last dense scan kernel on this handle (HIP events, ms). */

@@ -70,6 +70,10 @@ def load():
             raise HipLibraryError(
                 f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # torch ships its own HIP runtime (libamdhip64, SONAME .7).  Importing it first makes
+        # the dynamic linker bind librr_hip.so to that same runtime; loaded the other way
+        # round the process would hold two runtimes and the second one sees no device.
+        import torch  # noqa: F401
         lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

@@ -282,7 +282,7 @@ extern "C" int rr_bm25_scores_at_dev(rr_bm25* bm, const int32_t* d_term_ids,
                "rr_bm25_scores_at_dev: n_queries %d / pool %d out of range", n_queries, pool);
     RR_REQUIRE(mode == 0 || mode == 1, "rr_bm25_scores_at_dev: mode must be 0 (forward) or 1 (postings)");
     RR_HIP_TRY(hipSetDevice(bm->device));
-    hipStream_t st = stream ? (hipStream_t)stream : bm->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
     dim3 grid((unsigned)((pool + RR_AT_CANDS - 1) / RR_AT_CANDS), (unsigned)n_queries);
     if (mode == 0)
         hipLaunchKernelGGL((rr_bm25_at<0>), grid, dim3(256), 0, st, rr_view(bm), d_term_ids, d_term_off,

@@ -497,7 +497,7 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
     RR_REQUIRE(ix->dtype == RR_DTYPE_F32, "rr_dense_topk_dev: only fp32 storage is built");
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
     const int slots = (int)rr_round_up(n_queries, 8);
     const int64_t total = (int64_t)slots * ix->dim_pad;
     hipLaunchKernelGGL(rr_pad_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,

@@ -381,7 +381,7 @@ extern "C" int rr_fuse_topk_dev(rr_index* ix, const rr_fuse_params* p, int32_t n
     if (rc) return rc;
     RR_REQUIRE(d_out_rows && d_out_cols && d_out_order, "rr_fuse_topk_dev: NULL output");
     RR_HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
     rr_fuse_dev_params fp;
     fp.p = *p;
     const int sat = p->trust_sat > 1 ? p->trust_sat : 1;
@@ -463,7 +463,7 @@ extern "C" int rr_index_gather_meta_dev(rr_index* ix, const int64_t* d_rows, int
     if (!ix->has_meta) { rr_set_error("rr_index_gather_meta_dev: index has no metadata"); return RR_E_STATE; }
     if (n == 0) return RR_OK;
     RR_HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t st = stream ? (hipStream_t)stream : ix->stream;
+    hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
     hipLaunchKernelGGL(rr_gather_meta, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_rows, n,
                        ix->row_offset, ix->n_rows, ix->d_n_reviews, ix->d_avg_stars, ix->d_log1p_n,
                        d_n_reviews, d_avg_stars, d_log1p_n);

@@ -35,4 +35,4 @@ def assert_topk_matches(rows, scores, ref_sims64, k, tie_eps=4e-7, score_tol=1e-
 
 def min_gap(ref_sims64, k):
     top = np.sort(ref_sims64)[::-1][:k + 1]
-    return float(np.min(-np.diff(top)))
+    return float(np.min(-np.diff(top))) if len(top) > 1 else float("inf")

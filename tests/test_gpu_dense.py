@@ -23,7 +23,7 @@ def check_against_oracle(V, Q, pool, index=None):
         assert_topk_matches(rows[i], scores[i], ref64, eff)
         # and against the reference-order oracle wherever its top-k has clear gaps
         o_rows, o_sims = OD.cosine_similarity_search(q, V, pool)
-        if min_gap(ref64, eff) > 1e-6:
+        if min_gap(ref64, eff) > 4e-7:
             assert np.array_equal(rows[i], o_rows), "IDs must be bit-exact"
         np.testing.assert_allclose(scores[i], o_sims[:eff] if len(o_sims) else o_sims, atol=1e-5, rtol=0)
     if index is None:
@@ -51,7 +51,7 @@ def test_golden_10k_from_reference_utils(golden_dense):
     rows, scores = ix.dense_topk(Q, k)
     for i in range(len(Q)):
         ref64 = OD.sims_float64(V, Q[i])
-        assert min_gap(ref64, k) > 1e-6            # the recipe has no near-ties: IDs must be exact
+        assert min_gap(ref64, k) > 4e-7            # the recipe has no near-ties: IDs must be exact
         assert np.array_equal(rows[i], golden_dense["rows"][i])
         np.testing.assert_allclose(scores[i], golden_dense["sims"][i], atol=1e-5, rtol=0)
     ix.close()
@@ -164,7 +164,7 @@ def test_one_million_rows_full_size():
                               for s in range(0, n, 100000)])
         assert_topk_matches(rows[i], scores[i], ref, 150)
         o_rows, o_sims = OD.cosine_similarity_search(Q[i], V, 150)
-        if min_gap(ref, 150) > 1e-6:
+        if min_gap(ref, 150) > 4e-7:
             assert np.array_equal(rows[i], o_rows)
     assert ix.last_scan_ms() > 0
     ix.close()
