@@ -91,6 +91,11 @@ int rr_index_last_scan_ms(rr_index* ix, float* out_ms);
 /* Every scan launch is bracketed by a HIP event pair on its stream (ring of 512).
  * Drains the pairs recorded since the last call: total ms and launch count. */
 int rr_index_scan_stats(rr_index* ix, double* out_total_ms, int64_t* out_launches);
+/* Path taken by the last top-pool selection for its first query: out4 = {1 if the
+ * LDS-resident 3-level path finished (0: generic radix fallback), groups opened, tiles
+ * opened, candidate rows}, out16[4..10] = shader-clock cycles of the selection's phases.
+ * Diagnostic: lets tests assert the fast path is the one running. */
+int rr_index_select_trace(rr_index* ix, int32_t* out16);
 
 /* ------------------------------------------------------------ K2 BM25 */
 

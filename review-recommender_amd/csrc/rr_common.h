@@ -48,6 +48,8 @@ struct rr_index {
     // scratch for K1 (grown on demand)
     float* d_sims = nullptr;     // [qcap][n_pad]
     float* d_gmax = nullptr;     // [qcap][n_tiles]
+    int32_t* d_sel_trace = nullptr;  // [8][4] path trace of the last selection launch
+    uint32_t* d_smax = nullptr;  // [qcap][n_super] ordered keys of super-tile maxima
     int32_t scratch_q = 0;
     float* d_q = nullptr;        // staged queries [RR_MAX_BATCH][dim_pad]
     int64_t* d_rows_out = nullptr;  // host-API staging [RR_MAX_BATCH][RR_MAX_POOL]

@@ -6,8 +6,10 @@
 //
 // Data layout in HBM
 //   M      n_rows x dim_pad fp32, row-major, dim_pad % 64 == 0 (zero padded)
-//   sims   [query][n_pad]   fp32, n_pad = 64 * n_tiles         (4 B / row / query)
-//   gmax   [query][n_tiles] fp32, max of each 64-row tile       (1/16 B / row / query)
+//   sims   [query][n_pad]    fp32, n_pad = 64 * n_tiles          (4 B / row / query)
+//   gmax   [query][n_tiles]  fp32, max of each 64-row tile        (1/16 B / row / query)
+//   smax   [query][n_waves]  u32 ordered key of the max of each wave's run of tiles
+//                            (a "group"; at most 8192 per query)
 //
 // rr_scan_f32: HBM-bound streaming kernel.  A 16-lane DPP row owns one matrix row:
 // lane j reads float4 j, j+16, ... of the row (NF = dim_pad/64 loads, each wave
@@ -15,23 +17,29 @@
 // chain over its 4*NF elements; the 16 partials are added by rr_row16_sum.
 // Every row therefore has the same summation order wherever it sits, so a
 // score does not depend on sharding, batch size or launch geometry.
-// A wave walks a 64-row tile in 16 steps of 4 rows, double-buffered in
-// registers (2 x NF loads of 16 B per lane in flight), keeps row (4*it+grp) in
-// lane (it + 16*grp), and ends the tile with one coalesced 256-B store of the
-// 64 scores plus their maximum.
+// A wave owns a contiguous run of `tiles_per_wave` 64-row tiles; it walks a tile in 16
+// steps of 4 rows, double-buffered in registers (2 x NF loads of 16 B per lane in
+// flight, prefetching across the tile seam), keeps row (4*it+grp) in lane
+// (it + 16*grp), and ends the tile with one 256-B store of the 64 scores plus
+// their maximum.  No atomics, no inter-wave traffic.
 //
-// rr_select: one 1024-thread workgroup per query.  The pool-th largest tile
-// maximum is a lower bound for the pool-th largest score, so only tiles whose
-// maximum reaches it are opened (~pool tiles x 256 B); the survivors are
-// ordered by the 64-bit key (score desc, row asc) in LDS.  Degenerate inputs
-// (massive ties, clustered rows) fall back to an 8-pass radix select over the
-// same key, still exact.
+// rr_select: one 1024-thread workgroup per query; see the comment on the kernel.
 #include "rr_common.h"
 
 #define RR_SCAN_THREADS 256
 #define RR_SEL_THREADS 1024
-#define RR_SEL_GCAP 4096   // tiles kept in LDS
-#define RR_SEL_CCAP 8192   // candidate rows kept in LDS
+#define RR_SEL_GCAP 4096    // slow path: tiles kept in LDS
+#define RR_SEL_CCAP 8192    // candidate rows kept in LDS
+#define RR_SEL_LCAP 256     // groups opened by the fast path
+
+// Geometry of one scan launch, shared by the scan and the selection.
+struct rr_scan_geom {
+    int64_t n_rows, n_tiles;
+    int64_t tiles_per_wave;   // C: wave w owns tiles [w*C, min((w+1)*C, n_tiles)) = one "group"
+    int32_t n_waves;          // waves of the launch; every one owns at least one tile
+    int32_t _pad;
+    int64_t n_pad;            // 64 * n_tiles
+};
 
 // ------------------------------------------------------------------ scan
 template <int NF>
@@ -43,11 +51,57 @@ __device__ __forceinline__ void rr_load_rows(f32x4 (&dst)[NF], const f32x4* __re
     for (int i = 0; i < NF; ++i) dst[i] = __builtin_nontemporal_load(p + 16 * i);
 }
 
+template <int NF, int NB, bool FROM_LDS>
+__device__ __forceinline__ void rr_dot_rows(const f32x4 (&x)[NF], const f32x4 (&qreg)[NF],
+                                            const f32x4 (*qs)[NF * 16], int sub, int it,
+                                            float (&mine)[NB]) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (FROM_LDS) asm volatile("" ::: "memory");  // keep one query slice live, re-read LDS
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            const f32x4 q = FROM_LDS ? qs[b][16 * i + sub] : qreg[i];
+            acc = __builtin_fmaf(x[i].x, q.x, acc);
+            acc = __builtin_fmaf(x[i].y, q.y, acc);
+            acc = __builtin_fmaf(x[i].z, q.z, acc);
+            acc = __builtin_fmaf(x[i].w, q.w, acc);
+        }
+        acc = rr_row16_sum(acc);
+        mine[b] = (sub == it) ? acc : mine[b];
+    }
+}
+
+// End of a tile: lane (sub, grp) holds row row0 + 4*sub + grp for every query.
+template <int NB>
+__device__ __forceinline__ void rr_finish_tile(const rr_scan_geom& G, int64_t tile, int64_t wave,
+                                               int64_t t0, int64_t t1, int lane, int sub, int grp,
+                                               float (&mine)[NB], float (&gm)[NB],
+                                               float* __restrict__ sims, float* __restrict__ gmax,
+                                               uint32_t* __restrict__ smax) {
+    const int64_t my_row = tile * 64 + 4 * sub + grp;
+    const bool valid = my_row < G.n_rows;
+    const bool group_end = tile == t1 - 1;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float v = mine[b];
+        v = (valid && v == v) ? v : -INFINITY;  // NaN scores and pad rows rank last
+        sims[(int64_t)b * G.n_pad + my_row] = v;
+        const float m = rr_wave_max(v);
+        gm[b] = fmaxf(gm[b], m);
+        if (lane == 0) {
+            gmax[(int64_t)b * G.n_tiles + tile] = m;
+            if (group_end)
+                smax[(int64_t)b * G.n_waves + wave] = rr_f2key(gm[b]);
+        }
+        if (group_end) gm[b] = -INFINITY;
+    }
+}
+
 template <int NF, int NB>
 __global__ __launch_bounds__(RR_SCAN_THREADS, (NB <= 1 ? 4 : 2)) void rr_scan_f32(
-    const f32x4* __restrict__ mat, int64_t n_rows, int64_t n_tiles,
-    const float* __restrict__ queries,  // NB x (NF*64)
-    float* __restrict__ sims, int64_t sims_stride, float* __restrict__ gmax, int64_t gmax_stride) {
+    const f32x4* __restrict__ mat, rr_scan_geom G, const float* __restrict__ queries,  // NB x (NF*64)
+    float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax) {
     __shared__ f32x4 qs[NB][NF * 16];
     const int tid = threadIdx.x;
     for (int i = tid; i < NB * NF * 16; i += RR_SCAN_THREADS)
@@ -58,101 +112,65 @@ __global__ __launch_bounds__(RR_SCAN_THREADS, (NB <= 1 ? 4 : 2)) void rr_scan_f3
     const int sub = lane & 15;
     const int grp = lane >> 4;
     const int64_t wave = (int64_t)blockIdx.x * (RR_SCAN_THREADS / 64) + (tid >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * (RR_SCAN_THREADS / 64);
+    if (wave >= G.n_waves) return;
+    const int64_t t0 = wave * G.tiles_per_wave;
+    const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
 
     // NB == 1 keeps the query slice in registers; larger tiles re-read LDS
     // (conflict-free: the four rows of a wave broadcast the same 16 float4).
-    f32x4 qreg[NB == 1 ? NF : 1];
-    if (NB == 1) {
+    f32x4 qreg[NF];
 #pragma unroll
-        for (int i = 0; i < NF; ++i) qreg[i] = qs[0][16 * i + sub];
-    }
+    for (int i = 0; i < NF; ++i) qreg[i] = (NB == 1) ? qs[0][16 * i + sub] : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float gm[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gm[b] = -INFINITY;
 
     f32x4 bufA[NF], bufB[NF];
-    int64_t tile = wave;
-    if (tile < n_tiles) rr_load_rows<NF>(bufA, mat, tile * 64 + grp, n_rows, sub);
-
-    while (tile < n_tiles) {
-        const int64_t next = tile + n_waves;
+    rr_load_rows<NF>(bufA, mat, t0 * 64 + grp, G.n_rows, sub);
+#pragma unroll 1
+    for (int64_t tile = t0; tile < t1; ++tile) {
         const int64_t row0 = tile * 64;
         float mine[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) mine[b] = 0.f;
-
 #pragma unroll(NB == 1 ? 8 : 1)
         for (int it = 0; it < 16; it += 2) {
-            rr_load_rows<NF>(bufB, mat, row0 + 4 * (it + 1) + grp, n_rows, sub);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (NB > 1) asm volatile("" ::: "memory");  // keep one query slice live, re-read LDS
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    const f32x4 q = (NB == 1) ? qreg[i] : qs[b][16 * i + sub];
-                    acc = __builtin_fmaf(bufA[i].x, q.x, acc);
-                    acc = __builtin_fmaf(bufA[i].y, q.y, acc);
-                    acc = __builtin_fmaf(bufA[i].z, q.z, acc);
-                    acc = __builtin_fmaf(bufA[i].w, q.w, acc);
-                }
-                acc = rr_row16_sum(acc);
-                mine[b] = (sub == it) ? acc : mine[b];
-            }
-            if (it + 2 < 16)
-                rr_load_rows<NF>(bufA, mat, row0 + 4 * (it + 2) + grp, n_rows, sub);
-            else
-                rr_load_rows<NF>(bufA, mat, (next < n_tiles ? next : tile) * 64 + grp, n_rows, sub);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (NB > 1) asm volatile("" ::: "memory");  // keep one query slice live, re-read LDS
-                float acc = 0.f;
-#pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    const f32x4 q = (NB == 1) ? qreg[i] : qs[b][16 * i + sub];
-                    acc = __builtin_fmaf(bufB[i].x, q.x, acc);
-                    acc = __builtin_fmaf(bufB[i].y, q.y, acc);
-                    acc = __builtin_fmaf(bufB[i].z, q.z, acc);
-                    acc = __builtin_fmaf(bufB[i].w, q.w, acc);
-                }
-                acc = rr_row16_sum(acc);
-                mine[b] = (sub == it + 1) ? acc : mine[b];
-            }
+            rr_load_rows<NF>(bufB, mat, row0 + 4 * (it + 1) + grp, G.n_rows, sub);
+            rr_dot_rows<NF, NB, (NB > 1)>(bufA, qreg, qs, sub, it, mine);
+            // it == 14 prefetches the first rows of the next tile (clamped on the last one)
+            rr_load_rows<NF>(bufA, mat, row0 + 4 * (it + 2) + grp, G.n_rows, sub);
+            rr_dot_rows<NF, NB, (NB > 1)>(bufB, qreg, qs, sub, it + 1, mine);
         }
-        // lane (sub, grp) now holds row row0 + 4*sub + grp for every query.
-        const int64_t my_row = row0 + 4 * sub + grp;
-        const bool valid = my_row < n_rows;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            float v = mine[b];
-            v = (valid && v == v) ? v : -INFINITY;  // NaN scores and pad rows rank last
-            sims[(int64_t)b * sims_stride + my_row] = v;
-            const float m = rr_wave_max(v);
-            if (lane == 0) gmax[(int64_t)b * gmax_stride + tile] = m;
-        }
-        tile = next;
+        rr_finish_tile<NB>(G, tile, wave, t0, t1, lane, sub, grp, mine, gm, sims, gmax, smax);
     }
 }
 
 // Generic-dimension variant (runtime NF); same per-row summation order.
 template <int NB>
 __global__ __launch_bounds__(RR_SCAN_THREADS) void rr_scan_f32_generic(
-    const f32x4* __restrict__ mat, int64_t n_rows, int64_t n_tiles, int nf,
-    const float* __restrict__ queries, float* __restrict__ sims, int64_t sims_stride,
-    float* __restrict__ gmax, int64_t gmax_stride) {
+    const f32x4* __restrict__ mat, rr_scan_geom G, int nf, const float* __restrict__ queries,
+    float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int sub = lane & 15;
     const int grp = lane >> 4;
     const int64_t wave = (int64_t)blockIdx.x * (RR_SCAN_THREADS / 64) + (tid >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * (RR_SCAN_THREADS / 64);
+    if (wave >= G.n_waves) return;
+    const int64_t t0 = wave * G.tiles_per_wave;
+    const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
     const f32x4* q4 = reinterpret_cast<const f32x4*>(queries);
-    for (int64_t tile = wave; tile < n_tiles; tile += n_waves) {
+    float gm[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) gm[b] = -INFINITY;
+    for (int64_t tile = t0; tile < t1; ++tile) {
         const int64_t row0 = tile * 64;
         float mine[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) mine[b] = 0.f;
         for (int it = 0; it < 16; ++it) {
             int64_t row = row0 + 4 * it + grp;
-            row = row < n_rows ? row : n_rows - 1;
+            row = row < G.n_rows ? row : G.n_rows - 1;
             const f32x4* p = mat + row * (int64_t)(nf * 16) + sub;
             float acc[NB];
 #pragma unroll
@@ -170,20 +188,11 @@ __global__ __launch_bounds__(RR_SCAN_THREADS) void rr_scan_f32_generic(
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const float s = rr_row16_sum(acc[b]);
-                mine[b] = (sub == it) ? s : mine[b];
+                const float sacc = rr_row16_sum(acc[b]);
+                mine[b] = (sub == it) ? sacc : mine[b];
             }
         }
-        const int64_t my_row = row0 + 4 * sub + grp;
-        const bool valid = my_row < n_rows;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            float v = mine[b];
-            v = (valid && v == v) ? v : -INFINITY;
-            sims[(int64_t)b * sims_stride + my_row] = v;
-            const float m = rr_wave_max(v);
-            if (lane == 0) gmax[(int64_t)b * gmax_stride + tile] = m;
-        }
+        rr_finish_tile<NB>(G, tile, wave, t0, t1, lane, sub, grp, mine, gm, sims, gmax, smax);
     }
 }
 
@@ -241,21 +250,15 @@ __device__ __forceinline__ void rr_bitonic_desc(uint64_t* keys, int n) {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
-    const float* __restrict__ sims, int64_t sims_stride, const float* __restrict__ gmax,
-    int64_t gmax_stride, int64_t n_rows, int64_t n_tiles, int pool, int64_t row_offset,
-    int64_t* __restrict__ out_rows, float* __restrict__ out_scores) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t wsum[4];
-    __shared__ uint32_t sel[2];
-    __shared__ uint32_t counters[2];
-    __shared__ uint32_t glist[RR_SEL_GCAP];
-    __shared__ uint64_t cand[RR_SEL_CCAP];
-
+// Exact for any input, but slow on large N: 8-bit radix passes over every tile maximum with
+// an LDS histogram (heavily contended when the keys share their top bits).  Kept as the
+// fallback of rr_select for inputs whose candidate lists overflow the fast path's LDS.
+// Leaves the ordered top-pool keys in cand[0..pool).
+__device__ void rr_select_slow(const float* __restrict__ s, const float* __restrict__ g,
+                               int64_t n_rows, int64_t n_tiles, int pool, uint32_t* hist,
+                               uint32_t* wsum, uint32_t* sel, uint32_t* counters, uint32_t* glist,
+                               uint64_t* cand) {
     const int tid = threadIdx.x;
-    const int q = blockIdx.x;
-    const float* s = sims + (int64_t)q * sims_stride;
-    const float* g = gmax + (int64_t)q * gmax_stride;
 
     // ---- 1. tau = pool-th largest tile maximum (or "everything" if few tiles)
     uint32_t tau_key = 0;
@@ -356,6 +359,233 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
     for (int i = tid; i < n_sort; i += RR_SEL_THREADS)
         if (i >= (int)n_cand) cand[i] = 0;
     rr_bitonic_desc(cand, n_sort);
+}
+
+// k-th largest of n (<= 8 * 1024) keys, each thread holding up to 8 of them in registers.
+// Bisection on the key bits, two bits per step (three trial thresholds), counting with wave
+// ballots: no atomics and no shuffles, so runs of equal keys (the usual state of the high
+// bits) cost nothing.  One barrier per step; the 3 x 16 per-wave counts are folded by every
+// wave with one LDS read per lane and a 16-lane DPP sum.
+// `max_steps` caps the bits resolved: the value returned is then a lower bound of the k-th
+// largest (count(key >= result) >= k always holds), which is all the selection needs.
+#define RR_SEL_RK 8
+template <int RK>
+__device__ uint32_t rr_kth_largest_reg(const uint32_t (&r)[RR_SEL_RK], int n_mine, uint32_t k,
+                                       uint32_t (*cnt)[3][16], int& phase, int max_steps) {
+    const int tid = threadIdx.x;
+    const int ln = tid & 63;
+    uint32_t mx = 0, mn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < RK; ++j)
+        if (j < n_mine) {
+            mx = r[j] > mx ? r[j] : mx;
+            mn = r[j] < mn ? r[j] : mn;
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t a = __shfl_xor(mx, m, 64), b = __shfl_xor(mn, m, 64);
+        mx = a > mx ? a : mx;
+        mn = b < mn ? b : mn;
+    }
+    if (ln == 0) {
+        cnt[phase][0][tid >> 6] = mx;
+        cnt[phase][1][tid >> 6] = mn;
+    }
+    __syncthreads();
+    for (int w = 0; w < 16; ++w) {
+        mx = cnt[phase][0][w] > mx ? cnt[phase][0][w] : mx;
+        mn = cnt[phase][1][w] < mn ? cnt[phase][1][w] : mn;
+    }
+    phase ^= 1;
+    if (mx == mn) return mx;
+    int bit = 31 - __clz(mx ^ mn);                        // highest bit in which keys differ
+    uint32_t prefix = (bit == 31) ? 0u : (mx >> (bit + 1)) << (bit + 1);
+    for (int step = 0; bit >= 0 && step < max_steps; ++step) {
+        const int lo = bit >= 1 ? bit - 1 : 0;            // this step decides bits [lo, bit]
+        const bool two = bit >= 1;
+        const uint32_t t1 = prefix | (1u << lo);                       // ..01
+        const uint32_t t2 = prefix | (1u << bit);                      // ..10 (or ..1)
+        const uint32_t t3 = prefix | (1u << bit) | (1u << lo);         // ..11
+        uint32_t c1 = 0, c2 = 0, c3 = 0;                               // wave-uniform counts
+#pragma unroll
+        for (int j = 0; j < RK; ++j) {
+            const bool have = j < n_mine;
+            c1 += (uint32_t)__popcll(__ballot(have && r[j] >= t1));
+            c2 += (uint32_t)__popcll(__ballot(have && r[j] >= t2));
+            c3 += (uint32_t)__popcll(__ballot(have && r[j] >= t3));
+        }
+        if (ln == 0) {
+            cnt[phase][0][tid >> 6] = c1;
+            cnt[phase][1][tid >> 6] = c2;
+            cnt[phase][2][tid >> 6] = c3;
+        }
+        __syncthreads();
+        int v = ln < 48 ? (int)(&cnt[phase][0][0])[ln] : 0;
+        v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+        const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane(v, 0);
+        const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane(v, 16);
+        const uint32_t s3 = (uint32_t)__builtin_amdgcn_readlane(v, 32);
+        phase ^= 1;
+        if (two) {
+            if (s3 >= k) prefix = t3;
+            else if (s2 >= k) prefix = t2;
+            else if (s1 >= k) prefix = t1;
+        } else if (s2 >= k) {
+            prefix = t2;
+        }
+        bit = lo - 1;
+    }
+    return prefix;
+}
+
+// Orders n (<= 1024) distinct keys descending by counting, for each key, the keys above it.
+__device__ void rr_rank_sort_desc(const uint64_t* keys, int n, uint64_t* out) {
+    const int tid = threadIdx.x;
+    uint64_t mine = 0;
+    int rank = 0;
+    if (tid < n) {
+        mine = keys[tid];
+        for (int j = 0; j < n; ++j) rank += keys[j] > mine ? 1 : 0;   // LDS broadcast reads
+    }
+    __syncthreads();
+    if (tid < n) out[rank] = mine;
+    __syncthreads();
+}
+
+// rr_select: one 1024-thread workgroup per query; exact top-pool by (score desc, row asc).
+//
+// The scan leaves three levels behind: the score of every row, the maximum of every 64-row
+// tile, and the maximum of every wave's run of tiles (a "group"; at most 8192 of them).
+// tau = the pool-th largest group maximum is a lower bound for the pool-th largest score:
+// at least `pool` groups hold a row that reaches it.  So one bisection over the group
+// maxima (in registers) fixes tau, and two filtering passes open only what can matter:
+//   groups with max >= tau (~pool)  ->  their tiles with max >= tau (~pool)  ->
+//   their rows with score >= tau (~pool + ties)  ->  ordered by the key (score, ~row).
+// If a list outgrows LDS (pool > 256, massive ties, clustered rows) the generic radix path
+// takes over; both are exact.
+__global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
+    rr_scan_geom G, const float* __restrict__ sims, const float* __restrict__ gmax,
+    const uint32_t* __restrict__ smax, int pool, int64_t row_offset,
+    int64_t* __restrict__ out_rows, float* __restrict__ out_scores, int32_t* __restrict__ dbg) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t cnt[2][3][16];
+    __shared__ uint32_t sel[2];
+    __shared__ uint32_t counters[4];
+    __shared__ uint32_t list2[RR_SEL_LCAP];     // groups opened
+    __shared__ uint32_t list1[RR_SEL_GCAP];     // tiles opened (aliased: the slow path's tile list)
+    __shared__ uint64_t cand[RR_SEL_CCAP];
+
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    const float* s = sims + (int64_t)q * G.n_pad;
+    const float* g = gmax + (int64_t)q * G.n_tiles;
+    const uint32_t* sm = smax + (int64_t)q * G.n_waves;
+    const int64_t n_rows = G.n_rows, n_tiles = G.n_tiles;
+    int phase = 0;
+    long long stamp[8];
+    int n_stamp = 0;
+#define RR_STAMP() do { if (n_stamp < 8) stamp[n_stamp++] = clock64(); } while (0)
+    RR_STAMP();
+    const int ng = G.n_waves;
+    bool fast = ng <= RR_SEL_RK * RR_SEL_THREADS;
+
+    if (tid < 4) counters[tid] = 0;
+    __syncthreads();
+
+    if (fast) {
+        // ---- tau: pool-th largest group maximum (every non-empty group if there are few)
+        uint32_t r[RR_SEL_RK];
+        int n_mine = 0;
+#pragma unroll
+        for (int j = 0; j < RR_SEL_RK; ++j) {
+            const int i = tid + j * RR_SEL_THREADS;
+            r[j] = i < ng ? sm[i] : 0u;
+            n_mine += i < ng ? 1 : 0;
+        }
+        // 7 two-bit steps below the highest differing bit: tau is within 2^-14 of the spread of
+        // the group maxima below the exact pool-th largest, i.e. it opens a handful more groups
+        uint32_t tau = 1u;
+        if (ng > pool) {
+            if (ng <= 1 * RR_SEL_THREADS) tau = rr_kth_largest_reg<1>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
+            else if (ng <= 2 * RR_SEL_THREADS) tau = rr_kth_largest_reg<2>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
+            else if (ng <= 4 * RR_SEL_THREADS) tau = rr_kth_largest_reg<4>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
+            else tau = rr_kth_largest_reg<8>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
+        }
+        if (tau == 0u) tau = 1u;                           // key 0 marks padding, never a score
+        RR_STAMP();   // 1: tau found
+#pragma unroll
+        for (int j = 0; j < RR_SEL_RK; ++j) {
+            if (j < n_mine && r[j] >= tau) {
+                const uint32_t slot = atomicAdd(&counters[0], 1u);
+                if (slot < RR_SEL_LCAP) list2[slot] = (uint32_t)(tid + j * RR_SEL_THREADS);
+            }
+        }
+        __syncthreads();
+        if (counters[0] > RR_SEL_LCAP) fast = false;
+
+        // ---- tiles of the opened groups whose maximum reaches tau
+        if (fast) {
+            const int C = (int)G.tiles_per_wave;
+            const int64_t n2 = (int64_t)counters[0] * C;
+            for (int64_t i = tid; i < n2; i += RR_SEL_THREADS) {
+                const int64_t t = (int64_t)list2[i / C] * C + (i % C);
+                if (t < n_tiles && rr_f2key(g[t]) >= tau) {
+                    const uint32_t slot = atomicAdd(&counters[1], 1u);
+                    if (slot < RR_SEL_GCAP) list1[slot] = (uint32_t)t;
+                }
+            }
+            __syncthreads();
+            if (counters[1] > RR_SEL_GCAP) fast = false;
+        }
+        RR_STAMP();   // 2: tiles listed
+        // ---- rows of the opened tiles whose score reaches tau
+        if (fast) {
+            const int n1 = (int)counters[1] * 64;
+            for (int i = tid; i < n1; i += RR_SEL_THREADS) {
+                const uint32_t row = list1[i >> 6] * 64u + (uint32_t)(i & 63);
+                if ((int64_t)row < n_rows) {
+                    const uint32_t key = rr_f2key(s[row]);
+                    if (key >= tau) {
+                        const uint32_t slot = atomicAdd(&counters[2], 1u);
+                        if (slot < RR_SEL_CCAP / 2)
+                            cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - row);
+                    }
+                }
+            }
+            __syncthreads();
+            RR_STAMP();   // 3: candidate rows listed
+            const uint32_t n_cand = counters[2];
+            if (n_cand > RR_SEL_CCAP / 2 || n_cand < (uint32_t)pool) {
+                fast = false;                              // massive ties at the cut
+            } else if (n_cand <= RR_SEL_THREADS) {
+                rr_rank_sort_desc(cand, (int)n_cand, cand + RR_SEL_CCAP / 2);
+                for (int i = tid; i < pool; i += RR_SEL_THREADS) cand[i] = cand[RR_SEL_CCAP / 2 + i];
+                __syncthreads();
+            } else {
+                int n_sort = 1;
+                while (n_sort < (int)n_cand) n_sort <<= 1;
+                for (int i = tid; i < n_sort; i += RR_SEL_THREADS)
+                    if (i >= (int)n_cand) cand[i] = 0;
+                rr_bitonic_desc(cand, n_sort);
+            }
+        }
+    }
+    RR_STAMP();   // 4: candidates ordered
+    if (tid == 0) {   // per-query trace of the path taken (read by rr_index_select_trace)
+        dbg[q * 16 + 0] = fast ? 1 : 0;
+        dbg[q * 16 + 1] = (int32_t)counters[0];
+        dbg[q * 16 + 2] = (int32_t)counters[1];
+        dbg[q * 16 + 3] = (int32_t)counters[2];
+        for (int i = 1; i < 8; ++i) dbg[q * 16 + 3 + i] = i < n_stamp ? (int32_t)(stamp[i] - stamp[i - 1]) : -1;
+    }
+    if (!fast) {
+        __syncthreads();
+        rr_select_slow(s, g, n_rows, n_tiles, pool, hist, wsum, sel, counters, list1, cand);
+    }
     for (int i = tid; i < pool; i += RR_SEL_THREADS) {
         const uint64_t key = cand[i];
         const uint32_t row = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
@@ -382,16 +612,22 @@ __global__ void rr_l2norm_f32(float* __restrict__ mat, int64_t n_rows, int dim_p
 }
 
 // ------------------------------------------------------------------ host side
+#define RR_MAX_SCAN_WAVES 8192   // 2048 workgroups x 4 waves: upper bound of any resident grid
+
 static int rr_ensure_scratch(rr_index* ix, int nq) {
     if (ix->scratch_q >= nq) return RR_OK;
     const int64_t n_tiles = rr_round_up(ix->n_rows, 64) / 64;
     if (ix->d_sims) hipFree(ix->d_sims);
     if (ix->d_gmax) hipFree(ix->d_gmax);
+    if (ix->d_smax) hipFree(ix->d_smax);
     ix->d_sims = nullptr;
     ix->d_gmax = nullptr;
+    ix->d_smax = nullptr;
     ix->scratch_q = 0;
+    const size_t groups_cap = (size_t)RR_MAX_SCAN_WAVES;   // one group maximum per scan wave
     RR_HIP_TRY(hipMalloc(&ix->d_sims, sizeof(float) * (size_t)nq * n_tiles * 64));
     RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * (size_t)nq * n_tiles));
+    RR_HIP_TRY(hipMalloc(&ix->d_smax, sizeof(uint32_t) * (size_t)nq * groups_cap));
     ix->scratch_q = nq;
     return RR_OK;
 }
@@ -405,45 +641,58 @@ static int rr_resident_grid(K kernel, int device) {
         per_cu = 2;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1)
         cus = 256;
-    return per_cu * cus;
+    int grid = per_cu * cus;
+    if (grid * (RR_SCAN_THREADS / 64) > RR_MAX_SCAN_WAVES) grid = RR_MAX_SCAN_WAVES / (RR_SCAN_THREADS / 64);
+    return grid;
+}
+
+// Splits the tiles into equal contiguous runs, one per wave of (at most) a resident grid.
+static rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks) {
+    rr_scan_geom G;
+    G.n_rows = ix->n_rows;
+    G.n_tiles = rr_round_up(ix->n_rows, 64) / 64;
+    G.n_pad = G.n_tiles * 64;
+    const int64_t max_waves = (int64_t)resident_blocks * (RR_SCAN_THREADS / 64);
+    G.tiles_per_wave = (G.n_tiles + max_waves - 1) / max_waves;
+    G.n_waves = (int32_t)((G.n_tiles + G.tiles_per_wave - 1) / G.tiles_per_wave);
+    G._pad = 0;
+    return G;
 }
 
 template <int NB>
-static void rr_launch_scan(rr_index* ix, const float* d_q, hipStream_t st, int grid) {
-    const int64_t n_tiles = rr_round_up(ix->n_rows, 64) / 64;
-    const int64_t n_pad = n_tiles * 64;
+static rr_scan_geom rr_launch_scan(rr_index* ix, const float* d_q, hipStream_t st) {
     const f32x4* mat = reinterpret_cast<const f32x4*>(ix->d_matrix);
     const int nf = ix->dim_pad / 64;
     static int cap6 = 0, capg = 0;   // per template instance
+    rr_scan_geom G;
     if (nf == 6) {
         if (!cap6) cap6 = rr_resident_grid(rr_scan_f32<6, NB>, ix->device);
-        if (grid > cap6) grid = cap6;
+        G = rr_make_geom(ix, cap6);
+        const int grid = (G.n_waves + 3) / 4;
+        hipLaunchKernelGGL((rr_scan_f32<6, NB>), dim3(grid), dim3(RR_SCAN_THREADS), 0, st, mat, G, d_q,
+                           ix->d_sims, ix->d_gmax, ix->d_smax);
     } else {
         if (!capg) capg = rr_resident_grid(rr_scan_f32_generic<NB>, ix->device);
-        if (grid > capg) grid = capg;
+        G = rr_make_geom(ix, capg);
+        const int grid = (G.n_waves + 3) / 4;
+        hipLaunchKernelGGL((rr_scan_f32_generic<NB>), dim3(grid), dim3(RR_SCAN_THREADS), 0, st, mat, G, nf,
+                           d_q, ix->d_sims, ix->d_gmax, ix->d_smax);
     }
-    if (nf == 6)
-        hipLaunchKernelGGL((rr_scan_f32<6, NB>), dim3(grid), dim3(RR_SCAN_THREADS), 0, st, mat,
-                           ix->n_rows, n_tiles, d_q, ix->d_sims, n_pad, ix->d_gmax, n_tiles);
-    else
-        hipLaunchKernelGGL((rr_scan_f32_generic<NB>), dim3(grid), dim3(RR_SCAN_THREADS), 0, st, mat,
-                           ix->n_rows, n_tiles, nf, d_q, ix->d_sims, n_pad, ix->d_gmax, n_tiles);
+    return G;
 }
 
 // Scan + select for up to 8 queries already on the device (padded to dim_pad).
 static int rr_dense_chunk(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                           float* d_scores, hipStream_t st, bool time_it) {
-    const int64_t n_tiles = rr_round_up(ix->n_rows, 64) / 64;
-    const int64_t n_pad = n_tiles * 64;
-    int grid = (int)((n_tiles + 3) / 4);  // capped to the resident grid in rr_launch_scan
     if (time_it) hipEventRecord(ix->ev0, st);
     const int slot = (int)(ix->ring_head % rr_index::kRing);
     hipEventRecord(ix->ring0[slot], st);
+    rr_scan_geom G;
     switch (nq) {
-        case 1: rr_launch_scan<1>(ix, d_q, st, grid); break;
-        case 2: rr_launch_scan<2>(ix, d_q, st, grid); break;
-        case 3: case 4: rr_launch_scan<4>(ix, d_q, st, grid); break;
-        default: rr_launch_scan<8>(ix, d_q, st, grid); break;
+        case 1: G = rr_launch_scan<1>(ix, d_q, st); break;
+        case 2: G = rr_launch_scan<2>(ix, d_q, st); break;
+        case 3: case 4: G = rr_launch_scan<4>(ix, d_q, st); break;
+        default: G = rr_launch_scan<8>(ix, d_q, st); break;
     }
     hipEventRecord(ix->ring1[slot], st);
     ix->ring_head++;
@@ -452,9 +701,8 @@ static int rr_dense_chunk(rr_index* ix, const float* d_q, int nq, int pool, int6
         hipEventRecord(ix->ev1, st);
         ix->timing_valid = true;
     }
-    hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, ix->d_sims, n_pad,
-                       ix->d_gmax, n_tiles, ix->n_rows, n_tiles, pool, ix->row_offset, d_rows,
-                       d_scores);
+    hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
@@ -545,6 +793,15 @@ extern "C" int rr_index_last_scan_ms(rr_index* ix, float* out_ms) {
     RR_HIP_TRY(hipSetDevice(ix->device));
     RR_HIP_TRY(hipEventSynchronize(ix->ev1));
     RR_HIP_TRY(hipEventElapsedTime(out_ms, ix->ev0, ix->ev1));
+    return RR_OK;
+}
+
+extern "C" int rr_index_select_trace(rr_index* ix, int32_t* out4) {
+    RR_REQUIRE(ix && out4, "rr_index_select_trace: NULL argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    RR_HIP_TRY(hipSetDevice(ix->device));
+    RR_HIP_TRY(hipDeviceSynchronize());
+    RR_HIP_TRY(hipMemcpy(out4, ix->d_sel_trace, sizeof(int32_t) * 16, hipMemcpyDeviceToHost));
     return RR_OK;
 }
 

@@ -99,6 +99,13 @@ class ProductIndex:
         _lib.check(_lib.load().rr_index_last_scan_ms(self._h, C.byref(ms)), "rr_index_last_scan_ms")
         return ms.value
 
+    def select_trace(self):
+        """(fast_path_taken, groups_opened, tiles_opened, candidate_rows, then cycle counts of
+        the selection's phases) for the first query of the last selection."""
+        out = (C.c_int32 * 16)()
+        _lib.check(_lib.load().rr_index_select_trace(self._h, out), "rr_index_select_trace")
+        return tuple(out)
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             _lib.load().rr_index_destroy(self._h)

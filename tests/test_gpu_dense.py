@@ -84,6 +84,14 @@ def test_batches_and_batch_invariance(batch):
     ix.close()
 
 
+@pytest.mark.parametrize("pool", [255, 256, 257, 1000, 2048])
+def test_large_pools_cross_the_fast_path_limits(pool):
+    # the 3-level selection opens at most 256 groups per level in LDS; larger pools fall back
+    V = synth.unit_rows(200_000, 384, 51)
+    Q = synth.unit_rows(2, 384, 52)
+    check_against_oracle(V, Q, pool)
+
+
 def test_exact_ties_resolve_to_the_smaller_row():
     V = synth.unit_rows(5000, 384, 21)
     V[100:4000:100] = V[7]                      # 39 exact copies of row 7
