@@ -266,6 +266,15 @@ def main():
     total_ms, launches = _scan_stats(index)
 
     if rank == 0:
+        # HBM traffic per launch from the PMC passes kept in profiles/ (FETCH_SIZE x2 on gfx950 +
+        # WRITE_SIZE, MI355X_MICROARCH.md): measured on this kernel at batch 1 / 10M rows; the same
+        # bytes-per-row ratio is applied to this run's rows.  null when no PMC summary is present.
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_scan_b1_10M.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                m = json.load(f)
+            traffic = int(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"] * n_local * DIM * 4)
         bytes_per_launch = n_local * DIM * 4      # algorithmic: the shard's matrix, read once per launch
         avg_ms = total_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
@@ -283,7 +292,7 @@ def main():
                        "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k,
                        "pool": pool, "parallelism": f"row-shard x{world} + 1 all-gather"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "rr_scan_f32", "launches": int(launches),
                          "avg_launch_ms": round(avg_ms, 5), "bytes_per_launch": bytes_per_launch,
                          "queries_per_launch": min(args.batch, 8)},

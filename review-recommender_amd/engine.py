@@ -90,24 +90,33 @@ class HybridSearcher:
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
-    def dense_pool(self, q_dev, pool: int):
-        """K1 on device tensors: (rows int64 (B,pool), scores float32 (B,pool))."""
+    def dense_pool(self, q_dev, pool: int, out=None):
+        """K1 on device tensors: (rows int64 (B,pool), scores float32 (B,pool)).
+        ``out`` = (rows, scores) tensors to write into (e.g. views of a shard payload)."""
         torch = _torch()
         B = q_dev.shape[0]
-        rows = torch.empty((B, pool), dtype=torch.int64, device=self.device)
-        dense = torch.empty((B, pool), dtype=torch.float32, device=self.device)
+        if out is not None:
+            rows, dense = out
+        else:
+            rows = torch.empty((B, pool), dtype=torch.int64, device=self.device)
+            dense = torch.empty((B, pool), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.rr_dense_topk_dev(self.index.handle, C.c_void_p(q_dev.data_ptr()), B, pool,
                                               C.c_void_p(rows.data_ptr()), C.c_void_p(dense.data_ptr()),
                                               self._stream()), "rr_dense_topk_dev")
         return rows, dense
 
-    def bm25_at(self, term_id_lists: Sequence[Sequence[int]], rows_dev, mode: str = "forward"):
+    def bm25_at(self, term_id_lists: Sequence[Sequence[int]], rows_dev, mode: str = "forward", out=None):
         """K2 on device tensors: float32 (B, pool) raw BM25 at the candidate rows."""
         torch = _torch()
         B, pool = rows_dev.shape
-        out = torch.zeros((B, pool), dtype=torch.float32, device=self.device)
         if self.bm25 is None or not any(len(t) for t in term_id_lists):
-            return out   # no index / no tokens -> zeros (app/app_product_search.py:202,204)
+            # no index / no tokens -> zeros (app/app_product_search.py:202,204)
+            if out is None:
+                return torch.zeros((B, pool), dtype=torch.float32, device=self.device)
+            out.zero_()
+            return out
+        if out is None:
+            out = torch.empty((B, pool), dtype=torch.float32, device=self.device)
         ids_dev, off_dev = self._stage_terms(term_id_lists)
         _lib.check(self.lib.rr_bm25_scores_at_dev(
             self.bm25.handle, C.c_void_p(ids_dev.data_ptr()), C.c_void_p(off_dev.data_ptr()), B,

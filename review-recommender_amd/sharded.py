@@ -109,11 +109,8 @@ class ShardedSearcher:
         lay = PayloadLayout(B, pool_local)
         buf = torch.empty(lay.nbytes, dtype=torch.uint8, device=s.device)
         v = lay.views(buf)
-        rows, dense = s.dense_pool(q_dev, pool_local)
-        bm = s.bm25_at(term_id_lists, rows, bm25_mode)
-        v["rows"].copy_(rows)
-        v["dense"].copy_(dense)
-        v["bm25"].copy_(bm)
+        s.dense_pool(q_dev, pool_local, out=(v["rows"], v["dense"]))   # K1 writes the payload in place
+        s.bm25_at(term_id_lists, v["rows"], bm25_mode, out=v["bm25"])  # K2 too
         _lib.check(s.lib.rr_index_gather_meta_dev(
             s.index.handle, C.c_void_p(v["rows"].data_ptr()), B * pool_local,
             C.c_void_p(v["n"].data_ptr()), C.c_void_p(v["avg"].data_ptr()),
@@ -133,6 +130,12 @@ class ShardedSearcher:
             # every rank must contribute the same count for the strided addressing
             assert pool_local == pool, "each shard needs at least `pool` rows"
         tl = term_id_lists if term_id_lists is not None else [[] for _ in range(B)]
+        if self.world == 1:
+            # nothing to exchange: K1 -> K2 -> K3 straight through, metadata read from the index
+            s = self.s
+            rows, dense = s.dense_pool(q_dev, pool)
+            bm = s.bm25_at(tl, rows, bm25_mode)
+            return s.fuse(HybridSearcher.make_params(w, min(k, pool), pool, pool, 0), B, rows, dense, bm)
         lay, buf = self.local_payload(q_dev, tl, pool_local, bm25_mode)
         gathered = exchange(buf, self.world, self.group)
         base = gathered.data_ptr()
