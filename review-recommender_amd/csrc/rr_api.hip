@@ -59,7 +59,7 @@ extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim
         e = hipEventCreate(&ix->ring0[i]);
         if (e == hipSuccess) e = hipEventCreate(&ix->ring1[i]);
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sel_trace, sizeof(int32_t) * 16 * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sel_trace, sizeof(int32_t) * 16 * 64);
     if (e == hipSuccess) e = hipMalloc(&ix->d_q, sizeof(float) * (size_t)RR_MAX_BATCH * ix->dim_pad);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_rows_out, sizeof(int64_t) * (size_t)RR_MAX_BATCH * RR_MAX_POOL);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_scores_out, sizeof(float) * (size_t)RR_MAX_BATCH * RR_MAX_POOL);

@@ -196,6 +196,146 @@ __global__ __launch_bounds__(RR_SCAN_THREADS) void rr_scan_f32_generic(
     }
 }
 
+// ------------------------------------------------------------------ batched scan (MFMA)
+// rr_scan_mfma_f32<NQT>: the same scan for 16*NQT queries per launch (NQT = 1, 2, 4) on the
+// f32-input matrix cores.  v_mfma_f32_16x16x4_f32 is exact f32 (a k-ordered fmaf chain) at the
+// f32 vector rate, but one MFMA reuses each operand dword 16 times, so LDS and VGPR traffic
+// per FLOP drop 16x and the kernel stays HBM-bound up to ~32 queries per pass
+// (2*B flop/byte against a ~20 flop/byte f32 ridge), compute-bound beyond.
+//
+// A 256-thread workgroup walks a contiguous run of 64-row tiles.  Rows are staged through LDS
+// in chunks of 64 rows x 16 float4 (16 KB, two buffers): global loads keep the coalesced
+// shape of rr_scan_f32 (16 lanes x 16 B = 256 contiguous bytes of a row; two chunks in flight
+// in registers), the LDS image is XOR-swizzled (slot = float4 ^ (row & 15)) so both the
+// ds_write_b128 and the fragment ds_read_b128 are conflict-free.  Wave w owns query tile
+// w % NQT (its 16 queries x 384 dims live in 96 VGPRs as MFMA B operands for the whole
+// launch) and NQT of the tile's four 16-row M-tiles.  Lane (r = lane&15, g = lane>>4) feeds
+// MFMA (chunk, j, c) with component c of float4 (g + 4j) of row r / query r: the k order is
+// a fixed permutation of 0..383, identical for every row, so scores are again independent of
+// where a row sits.  (The order differs from rr_scan_f32's, so the two kernels agree to f32
+// rounding, ~1e-8, not bit for bit.)
+// Epilogue per tile: accumulators -> float4 stores of 4 consecutive rows of one query, tile
+// maxima via two xor-shuffles (+ one LDS hop when a query tile is shared by several waves).
+template <int NQT>
+__global__ __launch_bounds__(256, 2) void rr_scan_mfma_f32(
+    const f32x4* __restrict__ mat, rr_scan_geom G, const float* __restrict__ queries,  // (16*NQT) x 384
+    float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax) {
+    constexpr int NF = 6;           // chunks of 16 float4 per 384-d row
+    constexpr int MT = NQT;         // M-tiles (16 rows) per wave
+    constexpr int SHARE = 4 / NQT;  // waves sharing one query tile
+    __shared__ f32x4 stage[2][64 * 16];
+    __shared__ float wmax[4][16];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int r = lane & 15;        // MFMA row / column index; also the float4 a lane loads
+    const int g = lane >> 4;        // MFMA k group; also the row-in-quad a lane loads
+    const int qt = w % NQT;
+    const int mpart = w / NQT;
+    const int64_t blk = blockIdx.x;
+    if (blk >= G.n_waves) return;   // "wave" of the geometry = one workgroup's run of tiles here
+    const int64_t t0 = blk * G.tiles_per_wave;
+    const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
+    const int64_t n_chunks = (t1 - t0) * NF;
+
+    // B operands: query (16*qt + r), float4 (16*ch + g + 4*j)
+    f32x4 qreg[NF][4];
+    {
+        const f32x4* q4 = reinterpret_cast<const f32x4*>(queries) + (int64_t)(16 * qt + r) * (NF * 16);
+#pragma unroll
+        for (int ch = 0; ch < NF; ++ch)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qreg[ch][j] = q4[16 * ch + g + 4 * j];
+    }
+
+    // staging: this thread moves float4 r of rows 16*w + 4*i + g (i = 0..3) of every chunk
+    auto load_chunk = [&](f32x4 (&dst)[4], int64_t n) {
+        n = n < n_chunks ? n : n_chunks - 1;
+        const int64_t tile = t0 + n / NF;
+        const int ch = (int)(n % NF);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t row = tile * 64 + 16 * w + 4 * i + g;
+            row = row < G.n_rows ? row : G.n_rows - 1;
+            dst[i] = __builtin_nontemporal_load(mat + row * (NF * 16) + 16 * ch + r);
+        }
+    };
+    auto store_chunk = [&](const f32x4 (&src)[4], int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 16 * w + 4 * i + g;
+            stage[buf][row * 16 + (r ^ (row & 15))] = src[i];
+        }
+    };
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gm = -INFINITY;           // running maximum of this workgroup's run (lanes g == 0, mpart == 0)
+
+    f32x4 regA[4], regB[4];
+    load_chunk(regA, 0);
+    load_chunk(regB, 1);
+    store_chunk(regA, 0);
+    __syncthreads();
+
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        const int64_t nbase = (tile - t0) * NF;
+#pragma unroll
+        for (int ch = 0; ch < NF; ++ch) {
+            const int buf = ch & 1;                         // NF is even: parity is static
+            // chunk n = nbase + ch is in stage[buf]; chunk n + 1 is in flight in regB (ch even) / regA (odd)
+            if (buf == 0) load_chunk(regA, nbase + ch + 2); else load_chunk(regB, nbase + ch + 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    a[m] = stage[buf][((mpart * MT + m) * 16 + r) * 16 + ((g + 4 * j) ^ r)];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, qreg[ch][j].x, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, qreg[ch][j].y, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, qreg[ch][j].z, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, qreg[ch][j].w, acc[m], 0, 0, 0);
+                }
+            }
+            if (ch == NF - 1) {
+                // ---- tile epilogue: lane (r, g) holds rows 16*mt + 4*g + {0..3} of query 16*qt + r
+                const int64_t qrow = (int64_t)(16 * qt + r);
+                float m4 = -INFINITY;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int64_t row0 = tile * 64 + (mpart * MT + m) * 16 + 4 * g;
+                    f32x4 v = acc[m];
+                    v.x = (row0 + 0 < G.n_rows && v.x == v.x) ? v.x : -INFINITY;
+                    v.y = (row0 + 1 < G.n_rows && v.y == v.y) ? v.y : -INFINITY;
+                    v.z = (row0 + 2 < G.n_rows && v.z == v.z) ? v.z : -INFINITY;
+                    v.w = (row0 + 3 < G.n_rows && v.w == v.w) ? v.w : -INFINITY;
+                    *reinterpret_cast<f32x4*>(sims + qrow * G.n_pad + row0) = v;
+                    m4 = fmaxf(m4, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                    acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                m4 = fmaxf(m4, __shfl_xor(m4, 16, 64));
+                m4 = fmaxf(m4, __shfl_xor(m4, 32, 64));
+                if (g == 0) wmax[w][r] = m4;
+            }
+            // publish chunk n + 1 for the next step
+            if (buf == 0) store_chunk(regB, 1); else store_chunk(regA, 0);
+            __syncthreads();
+            if (ch == NF - 1 && mpart == 0 && g == 0) {
+                float m = wmax[qt][r];
+#pragma unroll
+                for (int p = 1; p < SHARE; ++p) m = fmaxf(m, wmax[qt + NQT * p][r]);
+                gmax[(int64_t)(16 * qt + r) * G.n_tiles + tile] = m;
+                gm = fmaxf(gm, m);
+            }
+        }
+    }
+    if (mpart == 0 && g == 0) smax[(int64_t)(16 * qt + r) * G.n_waves + blk] = rr_f2key(gm);
+}
+
 // ------------------------------------------------------------------ select
 // Suffix scan over a 256-bin histogram: finds the bin holding the k-th largest
 // element (counting from the top bin) and the count strictly above it.
@@ -707,18 +847,54 @@ static int rr_dense_chunk(rr_index* ix, const float* d_q, int nq, int pool, int6
     return RR_OK;
 }
 
+#define RR_MFMA_MAXQ 64   // queries per rr_scan_mfma_f32 launch
+
+// Scan + select for 9..64 queries on the matrix cores (fp32 storage, dim 384 only).
+template <int NQT>
+static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                               float* d_scores, hipStream_t st) {
+    static int cap = 0;
+    if (!cap) cap = rr_resident_grid(rr_scan_mfma_f32<NQT>, ix->device);
+    rr_scan_geom G = rr_make_geom(ix, cap / (RR_SCAN_THREADS / 64));   // one run of tiles per WORKGROUP
+    const int slot = (int)(ix->ring_head % rr_index::kRing);
+    hipEventRecord(ix->ring0[slot], st);
+    hipLaunchKernelGGL((rr_scan_mfma_f32<NQT>), dim3(G.n_waves), dim3(256), 0, st,
+                       reinterpret_cast<const f32x4*>(ix->d_matrix), G, d_q, ix->d_sims, ix->d_gmax, ix->d_smax);
+    hipEventRecord(ix->ring1[slot], st);
+    ix->ring_head++;
+    if (ix->ring_head - ix->ring_tail > rr_index::kRing) ix->ring_tail = ix->ring_head - rr_index::kRing;
+    hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
 static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int pool,
                               int64_t* d_rows, float* d_scores, hipStream_t st) {
     RR_HIP_TRY(hipSetDevice(ix->device));
-    int rc = rr_ensure_scratch(ix, 8);
+    const bool mfma_ok = ix->dim_pad == 384 && ix->n_rows >= 64;
+    int rc = rr_ensure_scratch(ix, (mfma_ok && nq > 8) ? RR_MFMA_MAXQ : 8);
     if (rc) return rc;
-    for (int q0 = 0; q0 < nq; q0 += 8) {
-        int n = nq - q0 < 8 ? nq - q0 : 8;
-        // the scan kernels read NB = 1/2/4/8 query slots; slots past n hold zeros
-        rc = rr_dense_chunk(ix, d_q_padded + (int64_t)q0 * ix->dim_pad, n, pool,
-                            d_rows + (int64_t)q0 * pool, d_scores + (int64_t)q0 * pool, st,
-                            q0 == 0);
+    int q0 = 0;
+    while (q0 < nq) {
+        const int left = nq - q0;
+        const float* q = d_q_padded + (int64_t)q0 * ix->dim_pad;
+        int64_t* rows = d_rows + (int64_t)q0 * pool;
+        float* scores = d_scores + (int64_t)q0 * pool;
+        int n;
+        if (mfma_ok && left > 8) {
+            // 9..64 queries share one read of the matrix on the matrix cores
+            n = left < RR_MFMA_MAXQ ? left : RR_MFMA_MAXQ;
+            if (n <= 16) rc = rr_dense_chunk_mfma<1>(ix, q, n, pool, rows, scores, st);
+            else if (n <= 32) rc = rr_dense_chunk_mfma<2>(ix, q, n, pool, rows, scores, st);
+            else rc = rr_dense_chunk_mfma<4>(ix, q, n, pool, rows, scores, st);
+        } else {
+            // the VALU scan kernels read NB = 1/2/4/8 query slots; slots past n hold zeros
+            n = left < 8 ? left : 8;
+            rc = rr_dense_chunk(ix, q, n, pool, rows, scores, st, q0 == 0);
+        }
         if (rc) return rc;
+        q0 += n;
     }
     return RR_OK;
 }
@@ -746,7 +922,7 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
-    const int slots = (int)rr_round_up(n_queries, 8);
+    const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);   // kernels read whole query tiles
     const int64_t total = (int64_t)slots * ix->dim_pad;
     hipLaunchKernelGGL(rr_pad_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        d_queries, ix->d_q, n_queries, ix->dim, ix->dim_pad, slots);
@@ -771,7 +947,7 @@ extern "C" int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_que
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = ix->stream;
-    const int slots = (int)rr_round_up(n_queries, 8);
+    const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);   // kernels read whole query tiles
     RR_HIP_TRY(hipMemsetAsync(ix->d_q, 0, sizeof(float) * (size_t)slots * ix->dim_pad, st));
     RR_HIP_TRY(hipMemcpy2DAsync(ix->d_q, sizeof(float) * ix->dim_pad, h_queries,
                                 sizeof(float) * ix->dim, sizeof(float) * ix->dim, n_queries,
