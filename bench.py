@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 DIM = 384
 SEED = 1234
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+F32_MATRIX_PEAK_TF = 157.3   # dense f32-input MFMA peak = f32 vector peak (MI355X_MICROARCH.md)
 N_BLOCKS = 8                 # the corpus is generated in 8 seeded blocks so any N in {1,2,4,8} sees the same data
 
 
@@ -43,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=10_000_000)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--vocab", type=int, default=200_000)
     ap.add_argument("--doc-len", type=int, default=40)
@@ -265,12 +266,29 @@ def main():
     dt = float(t.item())
     total_ms, launches = _scan_stats(index)
 
+    # the HBM-bound end of the path: one query per matrix read (rr_scan_f32<6,1>), same shard
+    q1 = qsets[0][0][:1].contiguous()
+    for _ in range(2):
+        sharded.s.dense_pool(q1, pool)
+    torch.cuda.synchronize()
+    _scan_stats(index)
+    for _ in range(10):
+        sharded.s.dense_pool(q1, pool)
+    torch.cuda.synchronize()
+    ms1, n1 = _scan_stats(index)
+    gbs1 = n_local * DIM * 4 / (ms1 / max(n1, 1) * 1e-3) / 1e9
+    single = {"bound": "hbm", "achieved": round(gbs1, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": round(gbs1 / HBM_PEAK_GBS, 4), "kernel": "rr_scan_f32<6,1>", "launches": int(n1),
+              "avg_launch_ms": round(ms1 / max(n1, 1), 5), "bytes_per_launch": n_local * DIM * 4}
+
     if rank == 0:
         # HBM traffic per launch from the PMC passes kept in profiles/ (FETCH_SIZE x2 on gfx950 +
-        # WRITE_SIZE, MI355X_MICROARCH.md): measured on this kernel at batch 1 / 10M rows; the same
-        # bytes-per-row ratio is applied to this run's rows.  null when no PMC summary is present.
+        # WRITE_SIZE, MI355X_MICROARCH.md), measured on this kernel at this many queries per launch
+        # on 10M rows; the same bytes-per-row ratio is applied to this run's rows.  null when no
+        # PMC summary for this launch shape is present.
+        qpl = min(args.batch, 64) if args.batch > 8 else min(args.batch, 8)   # queries sharing one matrix read
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic_scan_b1_10M.json")
+        pmc = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_scan_b{qpl}_10M.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 m = json.load(f)
@@ -278,6 +296,20 @@ def main():
         bytes_per_launch = n_local * DIM * 4      # algorithmic: the shard's matrix, read once per launch
         avg_ms = total_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        if qpl > 32:
+            # > 32 queries per read: 2*B flop/byte is past the f32 ridge (~20): the scan is bound by the
+            # f32-input matrix cores (exact f32, v_mfma_f32_16x16x4_f32), not by HBM
+            flops = 2.0 * n_local * DIM * qpl
+            tf = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
+            roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(tf / F32_MATRIX_PEAK_TF, 4), "traffic": traffic,
+                    "kernel": "rr_scan_mfma_f32<4>", "hbm_read_gbs": round(achieved, 2)}
+        else:
+            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "kernel": "rr_scan_f32" if qpl <= 8 else "rr_scan_mfma_f32"}
+        roof.update({"launches": int(launches), "avg_launch_ms": round(avg_ms, 5),
+                     "bytes_per_launch": bytes_per_launch, "queries_per_launch": qpl})
         out = {
             "metric": "queries/sec at top-k=100 (hybrid alpha=0.5)" if not args.no_bm25
                       else "queries/sec at top-k=100 (dense only)",
@@ -288,14 +320,13 @@ def main():
             "config": {"workload": (f"{'hybrid BM25+dense alpha=0.5' if not args.no_bm25 else 'dense-only cosine'} "
                                     f"top-k={args.k} pool={pool}, {args.docs} products x {DIM} fp32"
                                     + (f", BM25 ~{args.doc_len} tokens/doc vocab {args.vocab} "
-                                       f"({stats['nnz']} postings on rank 0)" if not args.no_bm25 else "")),
+                                       f"({stats['nnz']} postings on rank 0)" if not args.no_bm25 else "")
+                                    + f", batches of {args.batch} queries"),
                        "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k,
                        "pool": pool, "parallelism": f"row-shard x{world} + 1 all-gather"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "rr_scan_f32", "launches": int(launches),
-                         "avg_launch_ms": round(avg_ms, 5), "bytes_per_launch": bytes_per_launch,
-                         "queries_per_launch": min(args.batch, 8)},
+            "roofline": roof,
+            # the single-query scan on the same shard: the HBM-bound end of the same path
+            "roofline_single_query": single,
         }
         if world == 1 and not args.no_cpu_baseline:
             sample_rows = min(n_local, 1_000_000)

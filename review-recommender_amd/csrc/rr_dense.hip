@@ -24,6 +24,8 @@
 // their maximum.  No atomics, no inter-wave traffic.
 //
 // rr_select: one 1024-thread workgroup per query; see the comment on the kernel.
+#include <stdlib.h>
+
 #include "rr_common.h"
 
 #define RR_SCAN_THREADS 256
@@ -37,7 +39,10 @@ struct rr_scan_geom {
     int64_t n_rows, n_tiles;
     int64_t tiles_per_wave;   // C: wave w owns tiles [w*C, min((w+1)*C, n_tiles)) = one "group"
     int32_t n_waves;          // waves of the launch; every one owns at least one tile
-    int32_t _pad;
+    int32_t qs;               // 0: scores are [query][n_pad], tile maxima [query][n_tiles] (rr_scan_f32)
+                              // Q: scores are [row / 16][Q][16], tile maxima [tile][Q], group maxima [wave][Q]
+                              //    (rr_scan_mfma_f32 with Q = 16 * NQT query slots: every store of a wave is
+                              //    one contiguous block of whole 128-B lines)
     int64_t n_pad;            // 64 * n_tiles
 };
 
@@ -199,141 +204,132 @@ __global__ __launch_bounds__(RR_SCAN_THREADS) void rr_scan_f32_generic(
 // ------------------------------------------------------------------ batched scan (MFMA)
 // rr_scan_mfma_f32<NQT>: the same scan for 16*NQT queries per launch (NQT = 1, 2, 4) on the
 // f32-input matrix cores.  v_mfma_f32_16x16x4_f32 is exact f32 (a k-ordered fmaf chain) at the
-// f32 vector rate, but one MFMA reuses each operand dword 16 times, so LDS and VGPR traffic
-// per FLOP drop 16x and the kernel stays HBM-bound up to ~32 queries per pass
+// f32 vector rate, but one MFMA reuses each operand dword 16 times, so operand traffic per
+// FLOP drops 16x and the kernel stays HBM-bound up to ~32 queries per pass
 // (2*B flop/byte against a ~20 flop/byte f32 ridge), compute-bound beyond.
 //
-// A 256-thread workgroup walks a contiguous run of 64-row tiles.  Rows are staged through LDS
-// in chunks of 64 rows x 16 float4 (16 KB, two buffers): global loads keep the coalesced
-// shape of rr_scan_f32 (16 lanes x 16 B = 256 contiguous bytes of a row; two chunks in flight
-// in registers), the LDS image is XOR-swizzled (slot = float4 ^ (row & 15)) so both the
-// ds_write_b128 and the fragment ds_read_b128 are conflict-free.  Wave w owns query tile
-// w % NQT (its 16 queries x 384 dims live in 96 VGPRs as MFMA B operands for the whole
-// launch) and NQT of the tile's four 16-row M-tiles.  Lane (r = lane&15, g = lane>>4) feeds
-// MFMA (chunk, j, c) with component c of float4 (g + 4j) of row r / query r: the k order is
-// a fixed permutation of 0..383, identical for every row, so scores are again independent of
-// where a row sits.  (The order differs from rr_scan_f32's, so the two kernels agree to f32
+// Like rr_scan_f32 every wave is an independent stream over its own contiguous run of
+// 64-row tiles: no barriers, no inter-wave traffic after the prologue.  Measured on this
+// chip the scan rate follows the bytes in flight per CU (Little's law at ~5-8 us loaded
+// latency), and only the register file can hold ~190 KB per CU: LDS-staged variants
+// (register or LDS-DMA staging, 64-96 KB in flight) stopped at 4.6-5.2 TB/s.  So:
+//   A operand  matrix rows go straight to VGPRs in fragment shape: lane (r = lane&15,
+//              g = lane>>4) loads float4 (g + 4j), j = 0..23, of row r of a 16-row M-tile.
+//              The 24 registers are a ring: as soon as the MFMAs of step j have consumed
+//              a register, the load of the same j of the NEXT M-tile is issued into it, so a
+//              wave keeps 24 KB in flight continuously (8 waves per CU: 192 KB).
+//   B operand  the 16*NQT queries sit in LDS for the whole launch, XOR-swizzled
+//              (slot = (f & ~15) | ((f ^ query) & 15)) so the fragment ds_read_b128 is
+//              conflict-free; one read feeds four MFMAs.
+// Lane (r, g) feeds MFMA (j, c) with component c of float4 (g + 4j) of row r / query r.
+// The 384 dims are cut into four quarters (j in [6q, 6q+6)), each with its own accumulator;
+// every score is (acc0 + acc1) + (acc2 + acc3), each acc a fixed fmaf chain, whatever NQT is
+// and wherever the row sits: scores do not depend on batch size (within this kernel),
+// sharding or grid.  (The order differs from rr_scan_f32's: the two kernels agree to f32
 // rounding, ~1e-8, not bit for bit.)
-// Epilogue per tile: accumulators -> float4 stores of 4 consecutive rows of one query, tile
-// maxima via two xor-shuffles (+ one LDS hop when a query tile is shared by several waves).
 template <int NQT>
-__global__ __launch_bounds__(256, 2) void rr_scan_mfma_f32(
+__global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_f32(
     const f32x4* __restrict__ mat, rr_scan_geom G, const float* __restrict__ queries,  // (16*NQT) x 384
     float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax) {
-    constexpr int NF = 6;           // chunks of 16 float4 per 384-d row
-    constexpr int MT = NQT;         // M-tiles (16 rows) per wave
-    constexpr int SHARE = 4 / NQT;  // waves sharing one query tile
-    __shared__ f32x4 stage[2][64 * 16];
-    __shared__ float wmax[4][16];
-
+    constexpr int ROWF4 = 96;
+    __shared__ f32x4 qs[NQT * 16 * ROWF4];
+    constexpr int THREADS = NQT == 4 ? 512 : 256;   // 64 queries = 96 KB of LDS: one workgroup per CU, 8 waves
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = tid >> 6;
-    const int r = lane & 15;        // MFMA row / column index; also the float4 a lane loads
-    const int g = lane >> 4;        // MFMA k group; also the row-in-quad a lane loads
-    const int qt = w % NQT;
-    const int mpart = w / NQT;
-    const int64_t blk = blockIdx.x;
-    if (blk >= G.n_waves) return;   // "wave" of the geometry = one workgroup's run of tiles here
-    const int64_t t0 = blk * G.tiles_per_wave;
-    const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
-    const int64_t n_chunks = (t1 - t0) * NF;
-
-    // B operands: query (16*qt + r), float4 (16*ch + g + 4*j)
-    f32x4 qreg[NF][4];
-    {
-        const f32x4* q4 = reinterpret_cast<const f32x4*>(queries) + (int64_t)(16 * qt + r) * (NF * 16);
-#pragma unroll
-        for (int ch = 0; ch < NF; ++ch)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) qreg[ch][j] = q4[16 * ch + g + 4 * j];
+    for (int i = tid; i < NQT * 16 * ROWF4; i += THREADS) {
+        const int q = i / ROWF4, f = i % ROWF4;
+        qs[q * ROWF4 + ((f & ~15) | ((f ^ q) & 15))] = reinterpret_cast<const f32x4*>(queries)[i];
     }
-
-    // staging: this thread moves float4 r of rows 16*w + 4*i + g (i = 0..3) of every chunk
-    auto load_chunk = [&](f32x4 (&dst)[4], int64_t n) {
-        n = n < n_chunks ? n : n_chunks - 1;
-        const int64_t tile = t0 + n / NF;
-        const int ch = (int)(n % NF);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int64_t row = tile * 64 + 16 * w + 4 * i + g;
-            row = row < G.n_rows ? row : G.n_rows - 1;
-            dst[i] = __builtin_nontemporal_load(mat + row * (NF * 16) + 16 * ch + r);
-        }
-    };
-    auto store_chunk = [&](const f32x4 (&src)[4], int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 16 * w + 4 * i + g;
-            stage[buf][row * 16 + (r ^ (row & 15))] = src[i];
-        }
-    };
-
-    f32x4 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float gm = -INFINITY;           // running maximum of this workgroup's run (lanes g == 0, mpart == 0)
-
-    f32x4 regA[4], regB[4];
-    load_chunk(regA, 0);
-    load_chunk(regB, 1);
-    store_chunk(regA, 0);
     __syncthreads();
 
-    for (int64_t tile = t0; tile < t1; ++tile) {
-        const int64_t nbase = (tile - t0) * NF;
+    const int lane = tid & 63;
+    const int r = lane & 15;
+    const int g = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * (THREADS / 64) + (tid >> 6);
+    if (wave >= G.n_waves) return;
+    const int64_t t0 = wave * G.tiles_per_wave;
+    const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
+    const int64_t m0 = t0 * 4, m1 = t1 * 4;          // 16-row M-tiles of this wave
+
+    auto row_ptr = [&](int64_t mt) {
+        int64_t row = mt * 16 + r;
+        row = row < G.n_rows ? row : G.n_rows - 1;   // tail rows re-read the last row; masked later
+        return mat + row * ROWF4 + g;
+    };
+
+    // The ring loads are issued from inline asm so that they stay interleaved with the MFMAs
+    // (hipcc sinks plain loads to the end of the iteration and waits vmcnt(0) at its top);
+    // the waits are therefore counted by hand.  RR_RING_WAIT(j) ties the wait to the register
+    // it guards ("+v"), so the MFMAs that read it cannot be scheduled above it.
+#define RR_RING_LOAD(dst, ptr, byteoff) \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(byteoff) : "memory")
+    // younger memory operations when the load of (M-tile, j) is needed: the 23 other ring loads
+    // plus the NQT score stores of the previous M-tile (its occasional tile-maximum stores only
+    // make the wait conservative)
+#define RR_RING_WAIT(reg) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(23 + NQT) : "memory")
+    f32x4 a[24];
+    {
+        const f32x4* p = row_ptr(m0);
 #pragma unroll
-        for (int ch = 0; ch < NF; ++ch) {
-            const int buf = ch & 1;                         // NF is even: parity is static
-            // chunk n = nbase + ch is in stage[buf]; chunk n + 1 is in flight in regB (ch even) / regA (odd)
-            if (buf == 0) load_chunk(regA, nbase + ch + 2); else load_chunk(regB, nbase + ch + 2);
+        for (int j = 0; j < 24; ++j) RR_RING_LOAD(a[j], p, 64 * j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first M-tile: nothing older to count against
+    }
+    float tile_max[NQT], gm[NQT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 a[MT];
+    for (int t = 0; t < NQT; ++t) tile_max[t] = gm[t] = -INFINITY;
+
+#pragma unroll 1
+    for (int64_t mt = m0; mt < m1; ++mt) {
+        const f32x4* pn = row_ptr(mt + 1 < m1 ? mt + 1 : mt);
+        f32x4 acc[NQT][4];
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    a[m] = stage[buf][((mpart * MT + m) * 16 + r) * 16 + ((g + 4 * j) ^ r)];
+        for (int t = 0; t < NQT; ++t)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].x, qreg[ch][j].x, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].y, qreg[ch][j].y, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].z, qreg[ch][j].z, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].w, qreg[ch][j].w, acc[m], 0, 0, 0);
-                }
+            for (int qd = 0; qd < 4; ++qd) acc[t][qd] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            const int f = g + 4 * j;
+            const int qd = j / 6;
+            RR_RING_WAIT(a[j]);
+            const f32x4 x = a[j];
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) {
+                const f32x4 b = qs[(16 * t + r) * ROWF4 + ((f & ~15) | ((f ^ r) & 15))];
+                acc[t][qd] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, b.x, acc[t][qd], 0, 0, 0);
+                acc[t][qd] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, b.y, acc[t][qd], 0, 0, 0);
+                acc[t][qd] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, b.z, acc[t][qd], 0, 0, 0);
+                acc[t][qd] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, b.w, acc[t][qd], 0, 0, 0);
             }
-            if (ch == NF - 1) {
-                // ---- tile epilogue: lane (r, g) holds rows 16*mt + 4*g + {0..3} of query 16*qt + r
-                const int64_t qrow = (int64_t)(16 * qt + r);
-                float m4 = -INFINITY;
+            // the same j of the next M-tile goes into the register just consumed
+            asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                         : "=v"(a[j]) : "v"(pn), "n"(64 * j), "v"(acc[NQT - 1][qd]) : "memory");
+        }
+        // lane (r, g) holds rows 4*g .. 4*g+3 of the M-tile for query 16*t + r
+        const int64_t row0 = mt * 16 + 4 * g;
+        const bool tile_end = (mt & 3) == 3;
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const int64_t row0 = tile * 64 + (mpart * MT + m) * 16 + 4 * g;
-                    f32x4 v = acc[m];
-                    v.x = (row0 + 0 < G.n_rows && v.x == v.x) ? v.x : -INFINITY;
-                    v.y = (row0 + 1 < G.n_rows && v.y == v.y) ? v.y : -INFINITY;
-                    v.z = (row0 + 2 < G.n_rows && v.z == v.z) ? v.z : -INFINITY;
-                    v.w = (row0 + 3 < G.n_rows && v.w == v.w) ? v.w : -INFINITY;
-                    *reinterpret_cast<f32x4*>(sims + qrow * G.n_pad + row0) = v;
-                    m4 = fmaxf(m4, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-                    acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                m4 = fmaxf(m4, __shfl_xor(m4, 16, 64));
-                m4 = fmaxf(m4, __shfl_xor(m4, 32, 64));
-                if (g == 0) wmax[w][r] = m4;
-            }
-            // publish chunk n + 1 for the next step
-            if (buf == 0) store_chunk(regB, 1); else store_chunk(regA, 0);
-            __syncthreads();
-            if (ch == NF - 1 && mpart == 0 && g == 0) {
-                float m = wmax[qt][r];
-#pragma unroll
-                for (int p = 1; p < SHARE; ++p) m = fmaxf(m, wmax[qt + NQT * p][r]);
-                gmax[(int64_t)(16 * qt + r) * G.n_tiles + tile] = m;
-                gm = fmaxf(gm, m);
+        for (int t = 0; t < NQT; ++t) {
+            f32x4 v = (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+            v.x = (row0 + 0 < G.n_rows && v.x == v.x) ? v.x : -INFINITY;   // NaN scores and pad rows rank last
+            v.y = (row0 + 1 < G.n_rows && v.y == v.y) ? v.y : -INFINITY;
+            v.z = (row0 + 2 < G.n_rows && v.z == v.z) ? v.z : -INFINITY;
+            v.w = (row0 + 3 < G.n_rows && v.w == v.w) ? v.w : -INFINITY;
+            // [M-tile][query slot][16 rows]: the wave's 16*NQT queries x 64 B form one contiguous block
+            *reinterpret_cast<f32x4*>(sims + ((mt * (16 * NQT) + 16 * t + r) * 16 + 4 * g)) = v;
+            float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+            m4 = fmaxf(m4, __shfl_xor(m4, 16, 64));
+            m4 = fmaxf(m4, __shfl_xor(m4, 32, 64));
+            tile_max[t] = fmaxf(tile_max[t], m4);
+            if (tile_end) {                              // fourth M-tile: the 64-row tile is complete
+                if (g == 0) gmax[(mt >> 2) * (16 * NQT) + 16 * t + r] = tile_max[t];
+                gm[t] = fmaxf(gm[t], tile_max[t]);
+                tile_max[t] = -INFINITY;
             }
         }
     }
-    if (mpart == 0 && g == 0) smax[(int64_t)(16 * qt + r) * G.n_waves + blk] = rr_f2key(gm);
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) smax[wave * (16 * NQT) + 16 * t + r] = rr_f2key(gm[t]);
+    }
 }
 
 // ------------------------------------------------------------------ select
@@ -394,7 +390,8 @@ __device__ __forceinline__ void rr_bitonic_desc(uint64_t* keys, int n) {
 // an LDS histogram (heavily contended when the keys share their top bits).  Kept as the
 // fallback of rr_select for inputs whose candidate lists overflow the fast path's LDS.
 // Leaves the ordered top-pool keys in cand[0..pool).
-__device__ void rr_select_slow(const float* __restrict__ s, const float* __restrict__ g,
+template <typename ScoreAt, typename TileMaxAt>
+__device__ void rr_select_slow(ScoreAt score_at, TileMaxAt tile_max_at,
                                int64_t n_rows, int64_t n_tiles, int pool, uint32_t* hist,
                                uint32_t* wsum, uint32_t* sel, uint32_t* counters, uint32_t* glist,
                                uint64_t* cand) {
@@ -408,7 +405,7 @@ __device__ void rr_select_slow(const float* __restrict__ s, const float* __restr
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             for (int64_t i = tid; i < n_tiles; i += RR_SEL_THREADS) {
-                const uint32_t key = rr_f2key(g[i]);
+                const uint32_t key = rr_f2key(tile_max_at(i));
                 if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
             }
             __syncthreads();
@@ -427,7 +424,7 @@ __device__ void rr_select_slow(const float* __restrict__ s, const float* __restr
     bool all_tiles = (n_tiles <= pool);
     if (!all_tiles) {
         for (int64_t i = tid; i < n_tiles; i += RR_SEL_THREADS) {
-            if (rr_f2key(g[i]) >= tau_key) {
+            if (rr_f2key(tile_max_at(i)) >= tau_key) {
                 const uint32_t slot = atomicAdd(&counters[0], 1u);
                 if (slot < RR_SEL_GCAP) glist[slot] = (uint32_t)i;
             }
@@ -443,7 +440,7 @@ __device__ void rr_select_slow(const float* __restrict__ s, const float* __restr
         const int64_t t = all_tiles ? (i >> 6) : (int64_t)glist[i >> 6];
         const int64_t row = t * 64 + (i & 63);
         if (row < n_rows) {
-            const uint32_t key = rr_f2key(s[row]);
+            const uint32_t key = rr_f2key(score_at(row));
             if (key >= tau_key) {
                 const uint32_t slot = atomicAdd(&counters[1], 1u);
                 if (slot < RR_SEL_CCAP)
@@ -466,7 +463,7 @@ __device__ void rr_select_slow(const float* __restrict__ s, const float* __restr
                 const int64_t t = all_tiles ? (i >> 6) : (int64_t)glist[i >> 6];
                 const int64_t row = t * 64 + (i & 63);
                 if (row < n_rows) {
-                    const uint64_t key = ((uint64_t)rr_f2key(s[row]) << 32) |
+                    const uint64_t key = ((uint64_t)rr_f2key(score_at(row)) << 32) |
                                          (uint64_t)(0xFFFFFFFFu - (uint32_t)row);
                     if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
                 }
@@ -484,16 +481,20 @@ __device__ void rr_select_slow(const float* __restrict__ s, const float* __restr
             const int64_t t = all_tiles ? (i >> 6) : (int64_t)glist[i >> 6];
             const int64_t row = t * 64 + (i & 63);
             if (row < n_rows) {
-                const uint64_t key = ((uint64_t)rr_f2key(s[row]) << 32) |
+                const uint64_t key = ((uint64_t)rr_f2key(score_at(row)) << 32) |
                                      (uint64_t)(0xFFFFFFFFu - (uint32_t)row);
-                if (key >= prefix) cand[atomicAdd(&counters[1], 1u)] = key;
+                if (key >= prefix) {
+                    const uint32_t slot = atomicAdd(&counters[1], 1u);
+                    if (slot < RR_SEL_CCAP) cand[slot] = key;
+                }
             }
         }
         __syncthreads();
-        n_cand = counters[1];  // == pool
+        n_cand = counters[1] < RR_SEL_CCAP ? counters[1] : RR_SEL_CCAP;  // == pool
     }
 
     // ---- 4. order the survivors (score desc, row asc) and emit the first pool
+    if (n_cand > RR_SEL_CCAP) n_cand = RR_SEL_CCAP;   // cannot happen for consistent inputs; never overrun LDS
     int n_sort = 1;
     while (n_sort < (int)n_cand) n_sort <<= 1;
     for (int i = tid; i < n_sort; i += RR_SEL_THREADS)
@@ -621,9 +622,17 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
 
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
-    const float* s = sims + (int64_t)q * G.n_pad;
-    const float* g = gmax + (int64_t)q * G.n_tiles;
-    const uint32_t* sm = smax + (int64_t)q * G.n_waves;
+    // the two score layouts (rr_scan_geom::qs)
+    const int QS = G.qs;
+    auto score_at = [&](int64_t row) -> float {
+        return QS ? sims[((row >> 4) * QS + q) * 16 + (row & 15)] : sims[(int64_t)q * G.n_pad + row];
+    };
+    auto tile_max_at = [&](int64_t t) -> float {
+        return QS ? gmax[t * QS + q] : gmax[(int64_t)q * G.n_tiles + t];
+    };
+    auto group_key_at = [&](int i) -> uint32_t {
+        return QS ? smax[(int64_t)i * QS + q] : smax[(int64_t)q * G.n_waves + i];
+    };
     const int64_t n_rows = G.n_rows, n_tiles = G.n_tiles;
     int phase = 0;
     long long stamp[8];
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
 #pragma unroll
         for (int j = 0; j < RR_SEL_RK; ++j) {
             const int i = tid + j * RR_SEL_THREADS;
-            r[j] = i < ng ? sm[i] : 0u;
+            r[j] = i < ng ? group_key_at(i) : 0u;
             n_mine += i < ng ? 1 : 0;
         }
         // 7 two-bit steps below the highest differing bit: tau is within 2^-14 of the spread of
@@ -673,7 +682,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
             const int64_t n2 = (int64_t)counters[0] * C;
             for (int64_t i = tid; i < n2; i += RR_SEL_THREADS) {
                 const int64_t t = (int64_t)list2[i / C] * C + (i % C);
-                if (t < n_tiles && rr_f2key(g[t]) >= tau) {
+                if (t < n_tiles && rr_f2key(tile_max_at(t)) >= tau) {
                     const uint32_t slot = atomicAdd(&counters[1], 1u);
                     if (slot < RR_SEL_GCAP) list1[slot] = (uint32_t)t;
                 }
@@ -688,7 +697,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
             for (int i = tid; i < n1; i += RR_SEL_THREADS) {
                 const uint32_t row = list1[i >> 6] * 64u + (uint32_t)(i & 63);
                 if ((int64_t)row < n_rows) {
-                    const uint32_t key = rr_f2key(s[row]);
+                    const uint32_t key = rr_f2key(score_at(row));
                     if (key >= tau) {
                         const uint32_t slot = atomicAdd(&counters[2], 1u);
                         if (slot < RR_SEL_CCAP / 2)
@@ -724,7 +733,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
     }
     if (!fast) {
         __syncthreads();
-        rr_select_slow(s, g, n_rows, n_tiles, pool, hist, wsum, sel, counters, list1, cand);
+        rr_select_slow(score_at, tile_max_at, n_rows, n_tiles, pool, hist, wsum, sel, counters, list1, cand);
     }
     for (int i = tid; i < pool; i += RR_SEL_THREADS) {
         const uint64_t key = cand[i];
@@ -795,7 +804,7 @@ static rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks) {
     const int64_t max_waves = (int64_t)resident_blocks * (RR_SCAN_THREADS / 64);
     G.tiles_per_wave = (G.n_tiles + max_waves - 1) / max_waves;
     G.n_waves = (int32_t)((G.n_tiles + G.tiles_per_wave - 1) / G.tiles_per_wave);
-    G._pad = 0;
+    G.qs = 0;
     return G;
 }
 
@@ -853,12 +862,23 @@ static int rr_dense_chunk(rr_index* ix, const float* d_q, int nq, int pool, int6
 template <int NQT>
 static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st) {
-    static int cap = 0;
-    if (!cap) cap = rr_resident_grid(rr_scan_mfma_f32<NQT>, ix->device);
-    rr_scan_geom G = rr_make_geom(ix, cap / (RR_SCAN_THREADS / 64));   // one run of tiles per WORKGROUP
+    constexpr int THREADS = NQT == 4 ? 512 : 256;
+    static int cap_waves = 0;
+    if (!cap_waves) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr_scan_mfma_f32<NQT>, THREADS, 0) != hipSuccess ||
+            per_cu < 1)
+            per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device) != hipSuccess || cus < 1)
+            cus = 256;
+        cap_waves = per_cu * cus * (THREADS / 64);
+        if (cap_waves > RR_MAX_SCAN_WAVES) cap_waves = RR_MAX_SCAN_WAVES;
+    }
+    rr_scan_geom G = rr_make_geom(ix, cap_waves / 4);  // one run of tiles per wave, like rr_scan_f32
+    G.qs = 16 * NQT;
     const int slot = (int)(ix->ring_head % rr_index::kRing);
     hipEventRecord(ix->ring0[slot], st);
-    hipLaunchKernelGGL((rr_scan_mfma_f32<NQT>), dim3(G.n_waves), dim3(256), 0, st,
+    hipLaunchKernelGGL((rr_scan_mfma_f32<NQT>), dim3((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), dim3(THREADS), 0, st,
                        reinterpret_cast<const f32x4*>(ix->d_matrix), G, d_q, ix->d_sims, ix->d_gmax, ix->d_smax);
     hipEventRecord(ix->ring1[slot], st);
     ix->ring_head++;

@@ -1,0 +1,74 @@
+"""The multi-GPU data path on ONE GPU: the corpus is cut into row shards that all live on
+cuda:0, every shard builds its payload exactly as a rank would (K1 + K2 + metadata gather into
+the packed buffer), the buffers are laid out as the all-gather would leave them, and K3 merges
++ fuses with the [rank][query][pool] addressing.  The result must equal the unsharded result
+bit for bit.  The collective itself is covered on CPU (gloo) in
+tests/test_sharded_gloo.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from review_recommender_amd import _lib, synth
+from review_recommender_amd.bm25 import BM25Corpus
+from review_recommender_amd.engine import FusionWeights, HybridSearcher
+from review_recommender_amd.index import ProductIndex
+from review_recommender_amd.sharded import PayloadLayout, ShardedSearcher, shard_bounds
+
+pytestmark = pytest.mark.gpu
+
+
+def build(V, n_rev, stars, corpus, lo, hi):
+    ix = ProductIndex(V[lo:hi], row_offset=lo)
+    ix.set_meta(n_rev[lo:hi], stars[lo:hi])
+    bm = corpus.slice(lo, hi).to_device(row_offset=lo)
+    return HybridSearcher(ix, bm)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("batch", [1, 5, 20])
+def test_sharded_equals_unsharded_bitwise(world, batch):
+    n, vocab = 40_000, 3000
+    V = synth.unit_rows(n, 384, 61)
+    V[1000] = V[39_000]                       # an exact tie across shards: the smaller row must win
+    n_rev, stars = synth.metadata(n, 62, nan_fraction=0.01)
+    ip, terms, tf, dl = synth.bm25_forward_csr(n, vocab, 30, 63)
+    corpus = BM25Corpus(ip, terms, tf, dl, vocab)
+    Q = synth.unit_rows(batch, 384, 64)
+    Q[0] = V[1000]
+    tl = synth.query_terms(batch, vocab, 65, np.bincount(terms, minlength=vocab))
+    w = FusionWeights(w_dense=0.5, w_bm25=0.3, w_rerank=0.0, w_prior=0.2, w_best=0.0, gate_penalty=1.0)
+    k, pool = 100, 150
+
+    whole = build(V, n_rev.astype(np.float64), stars, corpus, 0, n)
+    ref = ShardedSearcher(whole, n, 0, 1)
+    q_dev = torch.from_numpy(Q).cuda()
+    want_rows, want_cols, want_order = [t.cpu().numpy() for t in ref.search_batch_dev(q_dev, tl, k, w)]
+
+    shards = []
+    for r in range(world):
+        lo, hi = shard_bounds(n, world, r)
+        shards.append(ShardedSearcher(build(V, n_rev.astype(np.float64), stars, corpus, lo, hi), n, r, world))
+    lay = PayloadLayout(batch, pool)
+    gathered = torch.empty((world, lay.nbytes), dtype=torch.uint8, device="cuda")
+    for r, sh in enumerate(shards):
+        _, buf = sh.local_payload(q_dev, tl, pool)
+        gathered[r].copy_(buf)
+    s0 = shards[0].s
+    params = HybridSearcher.make_params(w, k, pool, world * pool, 0, cand_per_rank=pool, stride_bytes=lay.nbytes)
+    out_rows = torch.empty((batch, pool), dtype=torch.int64, device="cuda")
+    cols = torch.empty((batch, 8, pool), dtype=torch.float64, device="cuda")
+    order = torch.empty((batch, k), dtype=torch.int32, device="cuda")
+    base = gathered.data_ptr()
+    p = lambda off: C.c_void_p(base + off)
+    _lib.check(s0.lib.rr_fuse_topk_dev(
+        s0.index.handle, C.byref(params), batch, p(lay.off_rows), p(lay.off_dense), p(lay.off_bm25),
+        p(lay.off_n), p(lay.off_avg), p(lay.off_l1p), None, None, None, C.c_void_p(out_rows.data_ptr()),
+        C.c_void_p(cols.data_ptr()), C.c_void_p(order.data_ptr()), s0._stream()), "rr_fuse_topk_dev")
+    torch.cuda.synchronize()
+    assert np.array_equal(out_rows.cpu().numpy(), want_rows)
+    assert np.array_equal(cols.cpu().numpy(), want_cols, equal_nan=True)
+    assert np.array_equal(order.cpu().numpy(), want_order)
+    r0 = want_rows[0].tolist()
+    assert r0.index(1000) + 1 == r0.index(39_000)      # tie: ascending global row
