@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--doc-len", type=int, default=40)
     ap.add_argument("--no-bm25", action="store_true", help="dense-only (BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-payload", action="store_true",
+                    help="diagnostic: with one rank, still pack / exchange / merge the shard payload")
     return ap.parse_args()
 
 
@@ -156,6 +158,7 @@ def build_shard(torch, dist, args, rank, world, dev):
         stats = dict(nnz=0, avgdl=0.0, df=None)
     searcher = HybridSearcher(index, bm25)
     sharded = ShardedSearcher(searcher, args.docs, rank, world)
+    sharded.force_payload = args.force_payload
     return sharded, index, keep, stats, n_local
 
 

@@ -1,0 +1,95 @@
+"""Command-line search, the reference's ``app/test.py`` on the GPU path.
+
+Same flags (app/test.py:345-361), same printed lines and JSON schema (app/test.py:312-342),
+CLI flavour of the pipeline (pool floor 100, no trust factor, BM25 aligned by sku permutation).
+
+    python -m review_recommender_amd.cli -q "wireless headphones" -k 10 --data-dir data/processed \
+        [--qvec-npy query.npy] [--json-out out.json]
+
+The query encoder (sentence-transformers BAAI/bge-small-en-v1.5) and the cross-encoder are
+loaded when the package is installed and the weights are on disk; offline, pass the query
+embedding with --qvec-npy and reranking degrades to zeros like the reference does when the
+model cannot be loaded (app/test.py:217-222).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+
+import numpy as np
+
+EMB_MODEL = os.environ.get("EMB_MODEL", "BAAI/bge-small-en-v1.5")           # app/test.py:28
+RERANK_MODEL = os.environ.get("RERANK_MODEL", "cross-encoder/ms-marco-MiniLM-L-6-v2")   # app/test.py:29
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(description="Search products with dense + (optional) BM25 + reranker + priors")
+    ap.add_argument("-q", "--query", required=True, help="User query")
+    ap.add_argument("-k", "--k", type=int, default=10, help="How many results to show")
+    ap.add_argument("--rerank_k", type=int, default=50, help="Cross-encoder rerank pool size (0 to disable)")
+    ap.add_argument("--no-snippets", action="store_true", help="accepted for compatibility; snippets are not scored")
+    ap.add_argument("--max-reviews-scan", type=int, default=1_000_000, help="accepted for compatibility")
+    ap.add_argument("--w-dense", type=float, default=0.55)
+    ap.add_argument("--w-bm25", type=float, default=0.15)
+    ap.add_argument("--w-rerank", type=float, default=0.15)
+    ap.add_argument("--w-prior", type=float, default=0.10)
+    ap.add_argument("--w-best", type=float, default=0.05)
+    ap.add_argument("--prior-C", type=float, default=20.0, help="Bayesian prior strength")
+    ap.add_argument("--gate-penalty", type=float, default=0.5, help="Penalty per missing attribute group (0.1-1.0)")
+    ap.add_argument("--json-out", type=str, default="", help="Optional path to save results JSON")
+    # additions of this build
+    ap.add_argument("--data-dir", type=str, default="data/processed", help="directory with the three artefacts")
+    ap.add_argument("--qvec-npy", type=str, default="", help=".npy with the query embedding (offline use)")
+    ap.add_argument("--device", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def _load_encoders():
+    enc = ce = None
+    try:
+        from sentence_transformers import CrossEncoder, SentenceTransformer
+        enc = SentenceTransformer(EMB_MODEL)
+        try:
+            ce = CrossEncoder(RERANK_MODEL)
+        except Exception as e:   # app/test.py:220-222
+            print(f"[warn] cross-encoder load failed: {e}; skipping reranker.", flush=True)
+    except Exception:
+        pass
+    return enc, ce
+
+
+def main(argv=None) -> int:
+    args = parse_args(argv)
+    from .artifacts import ArtifactError
+    from .engine import SearchEngine, cli_rows
+    qvec = np.load(args.qvec_npy).astype(np.float32).reshape(-1) if args.qvec_npy else None
+    enc, ce = (None, None) if qvec is not None else _load_encoders()
+    if qvec is None and enc is None:
+        raise SystemExit(f"[ERR] loading/encoding with {EMB_MODEL} failed: sentence-transformers or its weights "
+                         "are unavailable; pass --qvec-npy")          # app/test.py:234-235
+    try:
+        engine = SearchEngine.from_artifacts(args.data_dir, encoder=enc, cross_encoder=ce, flavour="cli",
+                                             device=args.device)
+    except ArtifactError as e:
+        raise SystemExit(f"[ERR] {e}")
+    frame, _, _ = engine.run_search(args.query, args.k, args.rerank_k, args.w_dense, args.w_bm25, args.w_rerank,
+                                    args.w_prior, args.w_best, args.prior_C, False, 0, 8, args.gate_penalty,
+                                    qvec=qvec)
+    rows = cli_rows(frame)
+    print("\nTop results:")
+    for i, r in enumerate(rows, 1):
+        print(f"[{i}] {r['sku']}  score={r['score']}  (dense={r['dense']} bm25={r['bm25']} rerank={r['rerank']} "
+              f"prior={r['prior']} best={r['bestrev']})  reviews={r['n_reviews']} avg={r['avg_stars']}")
+    if args.json_out:
+        pathlib.Path(args.json_out).parent.mkdir(parents=True, exist_ok=True)
+        with open(args.json_out, "w") as f:
+            json.dump({"query": args.query, "results": rows}, f, ensure_ascii=False, indent=2)
+        print(f"\n[ok] wrote {args.json_out}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

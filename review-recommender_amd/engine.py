@@ -241,7 +241,8 @@ class SearchEngine:
         self.flavour = flavour
         self.meta = meta.reset_index(drop=True)
         self.encoder, self.cross_encoder = encoder, cross_encoder
-        self.index = ProductIndex(embeddings, device=device, normalize=normalize)
+        # chunked upload: the matrix may be a memory-mapped product_emb.npy (app/test.py:140)
+        self.index = ProductIndex.from_rows(embeddings, device=device, normalize=normalize)
         nan = pd.Series([np.nan] * len(self.meta))
         n = pd.to_numeric(self.meta.get("n_reviews", nan), errors="coerce").fillna(0).values
         r = pd.to_numeric(self.meta.get("avg_stars", nan), errors="coerce").values
@@ -254,6 +255,16 @@ class SearchEngine:
             aligned = self.bm25_corpus.select(self._align_bm25([str(s) for s in bm25_blob["skus"]]))
             bm25_index = aligned.to_device(device)
         self.searcher = HybridSearcher(self.index, bm25_index)
+
+    @classmethod
+    def from_artifacts(cls, data_dir, **kw) -> "SearchEngine":
+        """Loads product_emb.npy / product_emb_meta.parquet / product_bm25.pkl from ``data_dir``
+        (the reference's data/processed layout, app/test.py:21-26) and l2-normalises the rows on
+        the GPU like the reference's loaders do on the host (app/test.py:144)."""
+        from .artifacts import load_artifacts
+        meta, emb, blob = load_artifacts(data_dir)
+        kw.setdefault("normalize", True)
+        return cls(meta, emb, blob, **kw)
 
     # app: sku -> last position, missing -> 0.0 score (app/app_product_search.py:207-208)
     # cli: same map, but if ANY meta sku is missing the scores are used unpermuted

@@ -48,6 +48,22 @@ class ProductIndex:
             self.l2_normalize(eps)
         self.has_meta = False
 
+    @classmethod
+    def from_rows(cls, rows, dim: Optional[int] = None, chunk_rows: int = 262_144, **kw) -> "ProductIndex":
+        """Builds the index from any (N, dim) array-like (e.g. a memory-mapped product_emb.npy),
+        uploading ``chunk_rows`` rows at a time so the host never holds a second copy."""
+        n = rows.shape[0]
+        dim = dim or rows.shape[1]
+        normalize = kw.pop("normalize", False)
+        ix = cls(None, n_rows=n, dim=dim, **kw)
+        lib = _lib.load()
+        for s in range(0, n, chunk_rows):
+            part = np.ascontiguousarray(rows[s:s + chunk_rows], dtype=np.float32)
+            _lib.check(lib.rr_index_upload_rows(ix._h, s, part.shape[0], _lib.ptr(part)), "rr_index_upload_rows")
+        if normalize:
+            ix.l2_normalize()
+        return ix
+
     @property
     def handle(self):
         return self._h

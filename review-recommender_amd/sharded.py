@@ -100,6 +100,8 @@ class ShardedSearcher:
             raise ValueError(f"rank {rank} must hold rows [{lo}, {hi}); its index holds "
                              f"[{ix.row_offset}, {ix.row_offset + ix.n_rows})")
         self.s, self.rank, self.world, self.group, self.n_total = searcher, rank, world, group, n_total_rows
+        # diagnostic: run the payload + exchange + merge path even with one rank (bench.py --force-payload)
+        self.force_payload = False
 
     def local_payload(self, q_dev, term_id_lists, pool_local: int, bm25_mode: str = "forward"):
         """K1 + K2 + metadata gather into the payload buffer of this rank."""
@@ -130,7 +132,7 @@ class ShardedSearcher:
             # every rank must contribute the same count for the strided addressing
             assert pool_local == pool, "each shard needs at least `pool` rows"
         tl = term_id_lists if term_id_lists is not None else [[] for _ in range(B)]
-        if self.world == 1:
+        if self.world == 1 and not self.force_payload:
             # nothing to exchange: K1 -> K2 -> K3 straight through, metadata read from the index
             s = self.s
             rows, dense = s.dense_pool(q_dev, pool)
