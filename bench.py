@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--vocab", type=int, default=200_000)
     ap.add_argument("--doc-len", type=int, default=40)
     ap.add_argument("--no-bm25", action="store_true", help="dense-only (BASELINE configs[1])")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="matrix storage (bf16: BASELINE configs[3]; queries and arithmetic stay fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-payload", action="store_true",
                     help="diagnostic: with one rank, still pack / exchange / merge the shard payload")
@@ -110,9 +112,15 @@ def build_shard(torch, dist, args, rank, world, dev):
         if want_bm25:
             parts.append((blk["doc_len"], blk["e_doc"] + s, blk["e_term"], blk["e_tf"]))
         del blk
-    index = ProductIndex(None, n_rows=n_local, dim=DIM, device=dev.index, row_offset=lo,
-                         device_ptr=mat.data_ptr(), keepalive=mat)
-    index.l2_normalize()                              # utils.py:40-44 on the device
+    if args.dtype == "bf16":
+        # normalise in fp32, round once to bf16 (nearest even): SURVEY section 8d
+        mat = (mat / torch.clamp(mat.norm(dim=1, keepdim=True), min=1e-12)).to(torch.bfloat16).contiguous()
+        index = ProductIndex(None, n_rows=n_local, dim=DIM, device=dev.index, row_offset=lo,
+                             device_ptr=mat.data_ptr(), keepalive=mat, dtype="bf16")
+    else:
+        index = ProductIndex(None, n_rows=n_local, dim=DIM, device=dev.index, row_offset=lo,
+                             device_ptr=mat.data_ptr(), keepalive=mat)
+        index.l2_normalize()                          # utils.py:40-44 on the device
     index.set_meta(n_rev.cpu().numpy(), stars.cpu().numpy())
 
     bm25 = None
@@ -279,10 +287,11 @@ def main():
         sharded.s.dense_pool(q1, pool)
     torch.cuda.synchronize()
     ms1, n1 = _scan_stats(index)
-    gbs1 = n_local * DIM * 4 / (ms1 / max(n1, 1) * 1e-3) / 1e9
+    gbs1 = n_local * DIM * (2 if args.dtype == "bf16" else 4) / (ms1 / max(n1, 1) * 1e-3) / 1e9
     single = {"bound": "hbm", "achieved": round(gbs1, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-              "frac": round(gbs1 / HBM_PEAK_GBS, 4), "kernel": "rr_scan_f32<6,1>", "launches": int(n1),
-              "avg_launch_ms": round(ms1 / max(n1, 1), 5), "bytes_per_launch": n_local * DIM * 4}
+              "frac": round(gbs1 / HBM_PEAK_GBS, 4), "kernel": "rr_scan_bf16<1>" if args.dtype == "bf16" else "rr_scan_f32<6,1>", "launches": int(n1),
+              "avg_launch_ms": round(ms1 / max(n1, 1), 5),
+              "bytes_per_launch": n_local * DIM * (2 if args.dtype == "bf16" else 4)}
 
     if rank == 0:
         # HBM traffic per launch from the PMC passes kept in profiles/ (FETCH_SIZE x2 on gfx950 +
@@ -295,8 +304,10 @@ def main():
         if os.path.exists(pmc):
             with open(pmc) as f:
                 m = json.load(f)
-            traffic = int(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"] * n_local * DIM * 4)
-        bytes_per_launch = n_local * DIM * 4      # algorithmic: the shard's matrix, read once per launch
+            if args.dtype == "f32":
+                traffic = int(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"] * n_local * DIM * 4)
+        esz = 2 if args.dtype == "bf16" else 4
+        bytes_per_launch = n_local * DIM * esz    # algorithmic: the shard's matrix, read once per launch
         avg_ms = total_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         if qpl > 32:
@@ -306,11 +317,12 @@ def main():
             tf = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
             roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                     "frac": round(tf / F32_MATRIX_PEAK_TF, 4), "traffic": traffic,
-                    "kernel": "rr_scan_mfma_f32<4>", "hbm_read_gbs": round(achieved, 2)}
+                    "kernel": "rr_scan_mfma_bf16<4>" if args.dtype == "bf16" else "rr_scan_mfma_f32<4>",
+                    "hbm_read_gbs": round(achieved, 2)}
         else:
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": "rr_scan_f32" if qpl <= 8 else "rr_scan_mfma_f32"}
+                    "kernel": ("rr_scan_" if qpl <= 8 else "rr_scan_mfma_") + args.dtype}
         roof.update({"launches": int(launches), "avg_launch_ms": round(avg_ms, 5),
                      "bytes_per_launch": bytes_per_launch, "queries_per_launch": qpl})
         out = {
@@ -320,8 +332,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "storage": args.dtype,
             "config": {"workload": (f"{'hybrid BM25+dense alpha=0.5' if not args.no_bm25 else 'dense-only cosine'} "
-                                    f"top-k={args.k} pool={pool}, {args.docs} products x {DIM} fp32"
+                                    f"top-k={args.k} pool={pool}, {args.docs} products x {DIM} {'bf16-stored' if args.dtype == 'bf16' else 'fp32'}"
                                     + (f", BM25 ~{args.doc_len} tokens/doc vocab {args.vocab} "
                                        f"({stats['nnz']} postings on rank 0)" if not args.no_bm25 else "")
                                     + f", batches of {args.batch} queries"),

@@ -38,7 +38,7 @@ extern "C" {
 #define RR_E_STATE      -4   /* handle not ready for this call (e.g. meta not set) */
 
 #define RR_DTYPE_F32     0
-#define RR_DTYPE_BF16    1   /* storage only; accumulation is always fp32 */
+#define RR_DTYPE_BF16    1   /* storage only (dim 384): queries, products and accumulation stay fp32 */
 
 #define RR_MAX_POOL   2048   /* upper bound for pool / k */
 #define RR_MAX_BATCH  1024
@@ -60,6 +60,11 @@ int rr_device_count(int* out);
 int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim, int32_t dtype,
                     int32_t device, int64_t row_offset, rr_index** out);
 int rr_index_upload_rows(rr_index* ix, int64_t first_row, int64_t n_rows, const void* h_rows);
+/* fp32 host rows into an index of either dtype: rows are optionally l2-normalised in fp32
+ * (normalize_eps > 0: utils.py:40-44) and then stored; a bf16 index rounds them once, to nearest
+ * even, AFTER the normalisation ("round V (RNE) to bf16 once"). */
+int rr_index_upload_rows_f32(rr_index* ix, int64_t first_row, int64_t n_rows, const float* h_rows,
+                             float normalize_eps);
 /* Use a caller-owned device matrix (n_rows x dim_padded(), already padded) without copying. */
 int rr_index_adopt_device(rr_index* ix, const void* d_matrix);
 int rr_index_dim_padded(const rr_index* ix, int32_t* out);

@@ -36,3 +36,11 @@ def topk_reference_order(sims: np.ndarray, top_k: int) -> Tuple[np.ndarray, np.n
 def sims_float64(embeddings_matrix: np.ndarray, query_vector: np.ndarray) -> np.ndarray:
     """Float64 dot products: the rounding-free yardstick for tolerance checks."""
     return embeddings_matrix.astype(np.float64) @ query_vector.astype(np.float64)
+
+
+def round_to_bf16(x: np.ndarray) -> np.ndarray:
+    """float32 -> nearest-even bfloat16, returned widened back to float32 (SURVEY section 8d:
+    the bf16 configs' oracle is the fp32 matvec over the matrix rounded ONCE to bf16)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+    return r.view(np.float32)

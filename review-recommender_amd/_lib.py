@@ -28,6 +28,7 @@ PROTOTYPES = {
     "rr_device_count": (C.c_int, [P(C.c_int)]),
     "rr_index_create": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i64, P(c_vp)]),
     "rr_index_upload_rows": (C.c_int, [c_vp, c_i64, c_i64, c_vp]),
+    "rr_index_upload_rows_f32": (C.c_int, [c_vp, c_i64, c_i64, c_vp, c_f32]),
     "rr_index_adopt_device": (C.c_int, [c_vp, c_vp]),
     "rr_index_dim_padded": (C.c_int, [c_vp, P(c_i32)]),
     "rr_index_l2_normalize": (C.c_int, [c_vp, c_f32]),

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "rr_common.h"
+#include "rr_dense.h"
 
 static thread_local char g_err[512] = "";
 
@@ -37,7 +38,8 @@ extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim
     RR_REQUIRE(n_rows >= 1 && n_rows < (1ll << 31), "rr_index_create: n_rows %lld out of [1, 2^31)",
                (long long)n_rows);
     RR_REQUIRE(dim >= 1 && dim <= 8192, "rr_index_create: dim %d out of [1, 8192]", dim);
-    RR_REQUIRE(dtype == RR_DTYPE_F32, "rr_index_create: dtype %d not built (fp32 only)", dtype);
+    RR_REQUIRE(dtype == RR_DTYPE_F32 || dtype == RR_DTYPE_BF16, "rr_index_create: unknown dtype %d", dtype);
+    RR_REQUIRE(dtype == RR_DTYPE_F32 || dim == 384, "rr_index_create: bf16 storage is built for dim 384 only");
     RR_REQUIRE(row_offset >= 0 && row_offset + n_rows < (1ll << 32),
                "rr_index_create: global rows must stay below 2^32");
     int ndev = 0;
@@ -106,6 +108,36 @@ extern "C" int rr_index_upload_rows(rr_index* ix, int64_t first_row, int64_t n_r
                                     hipMemcpyHostToDevice, ix->stream));
     RR_HIP_TRY(hipStreamSynchronize(ix->stream));
     return RR_OK;
+}
+
+extern "C" int rr_index_upload_rows_f32(rr_index* ix, int64_t first_row, int64_t n_rows, const float* h_rows,
+                                        float normalize_eps) {
+    RR_REQUIRE(ix && h_rows, "rr_index_upload_rows_f32: NULL argument");
+    RR_REQUIRE(first_row >= 0 && n_rows >= 0 && first_row + n_rows <= ix->n_rows,
+               "rr_index_upload_rows_f32: rows [%lld,%lld) outside [0,%lld)", (long long)first_row,
+               (long long)(first_row + n_rows), (long long)ix->n_rows);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    RR_HIP_TRY(hipSetDevice(ix->device));
+    RR_REQUIRE(ix->owns_matrix || !ix->d_matrix, "rr_index_upload_rows_f32: matrix is caller-owned");
+    int rc = rr_alloc_matrix(ix);
+    if (rc || n_rows == 0) return rc;
+    if (ix->dtype == RR_DTYPE_F32) {
+        char* dst = (char*)ix->d_matrix + (size_t)first_row * ix->dim_pad * 4;
+        RR_HIP_TRY(hipMemcpy2DAsync(dst, 4 * (size_t)ix->dim_pad, h_rows, 4 * (size_t)ix->dim, 4 * (size_t)ix->dim,
+                                    (size_t)n_rows, hipMemcpyHostToDevice, ix->stream));
+        if (normalize_eps > 0.f) rc = rr_l2norm_rows_f32(ix, first_row, n_rows, normalize_eps, ix->stream);
+    } else {
+        float* tmp = nullptr;
+        RR_HIP_TRY(hipMalloc((void**)&tmp, sizeof(float) * (size_t)n_rows * ix->dim));
+        hipError_t e = hipMemcpyAsync(tmp, h_rows, sizeof(float) * (size_t)n_rows * ix->dim, hipMemcpyHostToDevice,
+                                      ix->stream);
+        if (e == hipSuccess) rc = rr_store_rows_bf16(ix, first_row, n_rows, tmp, normalize_eps, ix->stream);
+        hipStreamSynchronize(ix->stream);
+        hipFree(tmp);
+        if (e != hipSuccess) { rr_set_error("rr_index_upload_rows_f32: %s", hipGetErrorString(e)); return RR_E_HIP; }
+    }
+    RR_HIP_TRY(hipStreamSynchronize(ix->stream));
+    return rc;
 }
 
 extern "C" int rr_index_adopt_device(rr_index* ix, const void* d_matrix) {

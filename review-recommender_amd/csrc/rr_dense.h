@@ -1,0 +1,40 @@
+// rr_dense.h -- pieces of K1 shared by the fp32 and bf16 scan files.
+#pragma once
+#include "rr_common.h"
+
+#define RR_SCAN_THREADS 256
+#define RR_MAX_SCAN_WAVES 8192   // 2048 workgroups x 4 waves: upper bound of any resident grid
+#define RR_MFMA_MAXQ 64          // queries per matrix-core scan launch
+
+// Geometry of one scan launch, shared by the scan and the selection.
+struct rr_scan_geom {
+    int64_t n_rows, n_tiles;
+    int64_t tiles_per_wave;   // C: wave w owns tiles [w*C, min((w+1)*C, n_tiles)) = one "group"
+    int32_t n_waves;          // waves of the launch; every one owns at least one tile
+    int32_t qs;               // 0: scores are [query][n_pad], tile maxima [query][n_tiles] (rr_scan_f32)
+                              // Q: scores are [row / 16][Q][16], tile maxima [tile][Q], group maxima [wave][Q]
+                              //    (rr_scan_mfma_f32 with Q = 16 * NQT query slots: every store of a wave is
+                              //    one contiguous block of whole 128-B lines)
+    int64_t n_pad;            // 64 * n_tiles
+};
+
+
+// Splits the tiles into equal contiguous runs, one per wave of (at most) `resident_blocks` x 4 waves.
+rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks);
+// HIP-event pair around a scan launch (rr_index_scan_stats).
+int rr_scan_events_begin(rr_index* ix, hipStream_t st);
+void rr_scan_events_end(rr_index* ix, int slot, hipStream_t st);
+// Exact top-pool of `nq` queries from the three score levels a scan left in the index scratch.
+void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
+                      float* d_scores, hipStream_t st);
+// Waves a kernel can keep resident on the device (occupancy x CUs x waves per workgroup).
+int rr_resident_waves(const void* kernel, int threads, int device);
+// bf16-storage scans (rr_dense_bf16.hip): up to 8 (VALU) or 9..64 (matrix cores) queries.
+int rr_dense_chunk_bf16(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                        float* d_scores, hipStream_t st);
+int rr_dense_chunk_mfma_bf16(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                             float* d_scores, hipStream_t st);
+// l2_normalize of rows [first, first + n) of an fp32 index, in place
+int rr_l2norm_rows_f32(rr_index* ix, int64_t first_row, int64_t n, float eps, hipStream_t st);
+// fp32 rows (device, n x dim) -> the index's bf16 matrix rows [first, first + n), optional l2 normalise
+int rr_store_rows_bf16(rr_index* ix, int64_t first_row, int64_t n, float* d_rows_f32, float eps, hipStream_t st);

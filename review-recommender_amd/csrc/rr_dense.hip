@@ -27,24 +27,12 @@
 #include <stdlib.h>
 
 #include "rr_common.h"
+#include "rr_dense.h"
 
-#define RR_SCAN_THREADS 256
 #define RR_SEL_THREADS 1024
 #define RR_SEL_GCAP 4096    // slow path: tiles kept in LDS
 #define RR_SEL_CCAP 8192    // candidate rows kept in LDS
 #define RR_SEL_LCAP 256     // groups opened by the fast path
-
-// Geometry of one scan launch, shared by the scan and the selection.
-struct rr_scan_geom {
-    int64_t n_rows, n_tiles;
-    int64_t tiles_per_wave;   // C: wave w owns tiles [w*C, min((w+1)*C, n_tiles)) = one "group"
-    int32_t n_waves;          // waves of the launch; every one owns at least one tile
-    int32_t qs;               // 0: scores are [query][n_pad], tile maxima [query][n_tiles] (rr_scan_f32)
-                              // Q: scores are [row / 16][Q][16], tile maxima [tile][Q], group maxima [wave][Q]
-                              //    (rr_scan_mfma_f32 with Q = 16 * NQT query slots: every store of a wave is
-                              //    one contiguous block of whole 128-B lines)
-    int64_t n_pad;            // 64 * n_tiles
-};
 
 // ------------------------------------------------------------------ scan
 template <int NF>
@@ -761,8 +749,6 @@ __global__ void rr_l2norm_f32(float* __restrict__ mat, int64_t n_rows, int dim_p
 }
 
 // ------------------------------------------------------------------ host side
-#define RR_MAX_SCAN_WAVES 8192   // 2048 workgroups x 4 waves: upper bound of any resident grid
-
 static int rr_ensure_scratch(rr_index* ix, int nq) {
     if (ix->scratch_q >= nq) return RR_OK;
     const int64_t n_tiles = rr_round_up(ix->n_rows, 64) / 64;
@@ -796,7 +782,7 @@ static int rr_resident_grid(K kernel, int device) {
 }
 
 // Splits the tiles into equal contiguous runs, one per wave of (at most) a resident grid.
-static rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks) {
+rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks) {
     rr_scan_geom G;
     G.n_rows = ix->n_rows;
     G.n_tiles = rr_round_up(ix->n_rows, 64) / 64;
@@ -806,6 +792,31 @@ static rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks) {
     G.n_waves = (int32_t)((G.n_tiles + G.tiles_per_wave - 1) / G.tiles_per_wave);
     G.qs = 0;
     return G;
+}
+
+int rr_scan_events_begin(rr_index* ix, hipStream_t st) {
+    const int slot = (int)(ix->ring_head % rr_index::kRing);
+    hipEventRecord(ix->ring0[slot], st);
+    return slot;
+}
+void rr_scan_events_end(rr_index* ix, int slot, hipStream_t st) {
+    hipEventRecord(ix->ring1[slot], st);
+    ix->ring_head++;
+    if (ix->ring_head - ix->ring_tail > rr_index::kRing) ix->ring_tail = ix->ring_head - rr_index::kRing;
+}
+void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
+                      float* d_scores, hipStream_t st) {
+    hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace);
+}
+int rr_resident_waves(const void* kernel, int threads, int device) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1)
+        cus = 256;
+    int waves = per_cu * cus * (threads / 64);
+    return waves > RR_MAX_SCAN_WAVES ? RR_MAX_SCAN_WAVES : waves;
 }
 
 template <int NB>
@@ -856,8 +867,6 @@ static int rr_dense_chunk(rr_index* ix, const float* d_q, int nq, int pool, int6
     return RR_OK;
 }
 
-#define RR_MFMA_MAXQ 64   // queries per rr_scan_mfma_f32 launch
-
 // Scan + select for 9..64 queries on the matrix cores (fp32 storage, dim 384 only).
 template <int NQT>
 static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
@@ -892,6 +901,7 @@ static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool,
 static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int pool,
                               int64_t* d_rows, float* d_scores, hipStream_t st) {
     RR_HIP_TRY(hipSetDevice(ix->device));
+    const bool bf16 = ix->dtype == RR_DTYPE_BF16;
     const bool mfma_ok = ix->dim_pad == 384 && ix->n_rows >= 64;
     int rc = rr_ensure_scratch(ix, (mfma_ok && nq > 8) ? RR_MFMA_MAXQ : 8);
     if (rc) return rc;
@@ -905,13 +915,15 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
         if (mfma_ok && left > 8) {
             // 9..64 queries share one read of the matrix on the matrix cores
             n = left < RR_MFMA_MAXQ ? left : RR_MFMA_MAXQ;
-            if (n <= 16) rc = rr_dense_chunk_mfma<1>(ix, q, n, pool, rows, scores, st);
+            if (bf16) rc = rr_dense_chunk_mfma_bf16(ix, q, n, pool, rows, scores, st);
+            else if (n <= 16) rc = rr_dense_chunk_mfma<1>(ix, q, n, pool, rows, scores, st);
             else if (n <= 32) rc = rr_dense_chunk_mfma<2>(ix, q, n, pool, rows, scores, st);
             else rc = rr_dense_chunk_mfma<4>(ix, q, n, pool, rows, scores, st);
         } else {
             // the VALU scan kernels read NB = 1/2/4/8 query slots; slots past n hold zeros
             n = left < 8 ? left : 8;
-            rc = rr_dense_chunk(ix, q, n, pool, rows, scores, st, q0 == 0);
+            rc = bf16 ? rr_dense_chunk_bf16(ix, q, n, pool, rows, scores, st)
+                      : rr_dense_chunk(ix, q, n, pool, rows, scores, st, q0 == 0);
         }
         if (rc) return rc;
         q0 += n;
@@ -938,7 +950,8 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
                "rr_dense_topk_dev: pool %d out of [1,min(%d,n_rows=%lld)]", pool, RR_MAX_POOL,
                (long long)ix->n_rows);
     RR_REQUIRE(ix->d_matrix, "rr_dense_topk_dev: index has no matrix");
-    RR_REQUIRE(ix->dtype == RR_DTYPE_F32, "rr_dense_topk_dev: only fp32 storage is built");
+    RR_REQUIRE(ix->dtype == RR_DTYPE_F32 || ix->dim_pad == 384,
+               "rr_dense_topk_dev: bf16 storage is built for dim 384 only");
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
@@ -963,7 +976,8 @@ extern "C" int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_que
     if (eff == 0) return RR_OK;  // top_k == 0 returns two empty arrays
     RR_REQUIRE(h_out_rows && h_out_scores, "rr_dense_topk: NULL output");
     RR_REQUIRE(ix->d_matrix, "rr_dense_topk: index has no matrix");
-    RR_REQUIRE(ix->dtype == RR_DTYPE_F32, "rr_dense_topk: only fp32 storage is built");
+    RR_REQUIRE(ix->dtype == RR_DTYPE_F32 || ix->dim_pad == 384,
+               "rr_dense_topk: bf16 storage is built for dim 384 only");
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = ix->stream;
@@ -1020,9 +1034,18 @@ extern "C" int rr_index_scan_stats(rr_index* ix, double* out_total_ms, int64_t* 
     return RR_OK;
 }
 
+int rr_l2norm_rows_f32(rr_index* ix, int64_t first_row, int64_t n, float eps, hipStream_t st) {
+    if (n == 0) return RR_OK;
+    hipLaunchKernelGGL(rr_l2norm_f32, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st,
+                       (float*)ix->d_matrix + first_row * ix->dim_pad, n, ix->dim_pad, eps);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
 extern "C" int rr_index_l2_normalize(rr_index* ix, float eps) {
     RR_REQUIRE(ix && ix->d_matrix, "rr_index_l2_normalize: index has no matrix");
-    RR_REQUIRE(ix->dtype == RR_DTYPE_F32, "rr_index_l2_normalize: only fp32 storage is built");
+    RR_REQUIRE(ix->dtype == RR_DTYPE_F32,
+               "rr_index_l2_normalize: a bf16 index is normalised in fp32 before rounding (rr_index_upload_rows_f32)");
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     const int rows_per_block = 4;

@@ -229,7 +229,7 @@ class SearchEngine:
 
     def __init__(self, meta: pd.DataFrame, embeddings: np.ndarray, bm25_blob: Optional[dict] = None,
                  *, encoder=None, cross_encoder=None, device: int = 0, normalize: bool = True,
-                 flavour: str = "app"):
+                 flavour: str = "app", dtype: str = "f32"):
         if flavour not in ("app", "cli"):
             raise ValueError("flavour must be 'app' or 'cli'")
         if len(meta) != embeddings.shape[0]:
@@ -242,7 +242,7 @@ class SearchEngine:
         self.meta = meta.reset_index(drop=True)
         self.encoder, self.cross_encoder = encoder, cross_encoder
         # chunked upload: the matrix may be a memory-mapped product_emb.npy (app/test.py:140)
-        self.index = ProductIndex.from_rows(embeddings, device=device, normalize=normalize)
+        self.index = ProductIndex.from_rows(embeddings, device=device, normalize=normalize, dtype=dtype)
         nan = pd.Series([np.nan] * len(self.meta))
         n = pd.to_numeric(self.meta.get("n_reviews", nan), errors="coerce").fillna(0).values
         r = pd.to_numeric(self.meta.get("avg_stars", nan), errors="coerce").values

@@ -11,6 +11,7 @@ from . import _lib
 
 MAX_POOL = 2048     # RR_MAX_POOL
 MAX_BATCH = 1024    # RR_MAX_BATCH
+DTYPES = {"f32": 0, "bf16": 1}   # RR_DTYPE_*
 
 
 class ProductIndex:
@@ -24,8 +25,14 @@ class ProductIndex:
     def __init__(self, matrix: Optional[np.ndarray] = None, *, n_rows: Optional[int] = None,
                  dim: Optional[int] = None, device: int = 0, row_offset: int = 0,
                  device_ptr: Optional[int] = None, normalize: bool = False, eps: float = 1e-12,
-                 keepalive=None):
+                 keepalive=None, dtype: str = "f32"):
         lib = _lib.load()
+        if dtype not in DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(DTYPES)}")
+        self.dtype = dtype
+        if matrix is not None and dtype != "f32":
+            raise ValueError("pass fp32 rows through ProductIndex.from_rows(..., dtype='bf16'): "
+                             "they are rounded once, after the fp32 normalisation")
         if matrix is not None:
             matrix = np.ascontiguousarray(matrix, dtype=np.float32)
             if matrix.ndim != 2:
@@ -35,7 +42,7 @@ class ProductIndex:
             raise ValueError("an index needs at least one row and one column")
         self.n_rows, self.dim, self.device, self.row_offset = int(n_rows), int(dim), device, row_offset
         h = C.c_void_p()
-        _lib.check(lib.rr_index_create(_lib.ptr(matrix), self.n_rows, self.dim, 0, device,
+        _lib.check(lib.rr_index_create(_lib.ptr(matrix), self.n_rows, self.dim, DTYPES[dtype], device,
                                        row_offset, C.byref(h)), "rr_index_create")
         self._h = h
         self._keepalive = keepalive
@@ -55,13 +62,14 @@ class ProductIndex:
         n = rows.shape[0]
         dim = dim or rows.shape[1]
         normalize = kw.pop("normalize", False)
+        eps = kw.pop("eps", 1e-12)
         ix = cls(None, n_rows=n, dim=dim, **kw)
         lib = _lib.load()
         for s in range(0, n, chunk_rows):
             part = np.ascontiguousarray(rows[s:s + chunk_rows], dtype=np.float32)
-            _lib.check(lib.rr_index_upload_rows(ix._h, s, part.shape[0], _lib.ptr(part)), "rr_index_upload_rows")
-        if normalize:
-            ix.l2_normalize()
+            # fp32 rows in; normalised in fp32 on the device if asked; a bf16 index rounds once, afterwards
+            _lib.check(lib.rr_index_upload_rows_f32(ix._h, s, part.shape[0], _lib.ptr(part),
+                                                    eps if normalize else 0.0), "rr_index_upload_rows_f32")
         return ix
 
     @property
