@@ -298,7 +298,7 @@ def main():
         # WRITE_SIZE, MI355X_MICROARCH.md), measured on this kernel at this many queries per launch
         # on 10M rows; the same bytes-per-row ratio is applied to this run's rows.  null when no
         # PMC summary for this launch shape is present.
-        qpl = min(args.batch, 64) if args.batch > 8 else min(args.batch, 8)   # queries sharing one matrix read
+        qpl = min(args.batch, 64) if args.batch > 4 else args.batch   # queries sharing one matrix read
         traffic = None
         pmc = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_scan_b{qpl}_10M.json")
         if os.path.exists(pmc):
@@ -322,7 +322,7 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": ("rr_scan_" if qpl <= 8 else "rr_scan_mfma_") + args.dtype}
+                    "kernel": ("rr_scan_" if qpl <= 4 else "rr_scan_mfma_") + args.dtype}
         roof.update({"launches": int(launches), "avg_launch_ms": round(avg_ms, 5),
                      "bytes_per_launch": bytes_per_launch, "queries_per_launch": qpl})
         out = {

@@ -17,6 +17,11 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import pandas as pd
 
+try:                     # bind the parquet engine before any GPU runtime is loaded (import-order
+    import pyarrow       # sensitivity seen on the GPU box)  # noqa: F401
+except ImportError:      # pandas will report the missing engine when a parquet file is touched
+    pass
+
 from . import text
 
 EMB_FILE = "product_emb.npy"

@@ -903,7 +903,11 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
     RR_HIP_TRY(hipSetDevice(ix->device));
     const bool bf16 = ix->dtype == RR_DTYPE_BF16;
     const bool mfma_ok = ix->dim_pad == 384 && ix->n_rows >= 64;
-    int rc = rr_ensure_scratch(ix, (mfma_ok && nq > 8) ? RR_MFMA_MAXQ : 8);
+    // measured crossover (10M rows): the per-row-chain VALU scans win up to 4 queries per read
+    // (2.4-2.5 ms fp32, 1.3-1.5 ms bf16); from 5 on the matrix-core scan does (2.7-2.9 / 1.8 ms
+    // for up to 16 queries, against 3.0 / 2.4 ms for the 8-query VALU scan)
+    const int valu_max = mfma_ok ? 4 : 8;
+    int rc = rr_ensure_scratch(ix, (mfma_ok && nq > valu_max) ? RR_MFMA_MAXQ : 8);
     if (rc) return rc;
     int q0 = 0;
     while (q0 < nq) {
@@ -912,8 +916,8 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
         int64_t* rows = d_rows + (int64_t)q0 * pool;
         float* scores = d_scores + (int64_t)q0 * pool;
         int n;
-        if (mfma_ok && left > 8) {
-            // 9..64 queries share one read of the matrix on the matrix cores
+        if (mfma_ok && left > valu_max) {
+            // 5..64 queries share one read of the matrix on the matrix cores
             n = left < RR_MFMA_MAXQ ? left : RR_MFMA_MAXQ;
             if (bf16) rc = rr_dense_chunk_mfma_bf16(ix, q, n, pool, rows, scores, st);
             else if (n <= 16) rc = rr_dense_chunk_mfma<1>(ix, q, n, pool, rows, scores, st);
@@ -921,7 +925,7 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
             else rc = rr_dense_chunk_mfma<4>(ix, q, n, pool, rows, scores, st);
         } else {
             // the VALU scan kernels read NB = 1/2/4/8 query slots; slots past n hold zeros
-            n = left < 8 ? left : 8;
+            n = left < valu_max ? left : valu_max;
             rc = bf16 ? rr_dense_chunk_bf16(ix, q, n, pool, rows, scores, st)
                       : rr_dense_chunk(ix, q, n, pool, rows, scores, st, q0 == 0);
         }

@@ -2,6 +2,11 @@ import json
 import pathlib
 import sys
 
+try:                     # parquet engine first: on the GPU box pandas could not import it once torch's
+    import pyarrow       # distributed stack had been loaded by test collection  # noqa: F401
+except ImportError:
+    pass
+
 import numpy as np
 import pytest
 

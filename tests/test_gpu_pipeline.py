@@ -178,15 +178,20 @@ def test_search_alpha_sugar_and_batch_api(world):
     assert frame["sku"].tolist() == want["sku"].tolist()
     np.testing.assert_allclose(frame["_final"].values, want["_final"].values, atol=TOL, rtol=0)
     assert dbg["pool"] == 150 and len(frame) == 100
-    # batch of 5 == five single calls, bitwise
-    Q = synth.unit_rows(5, 384, 56)
-    toks = [engine.searcher.bm25.term_ids(["wireless", "mug"])] * 5
+    # a batch of <= 4 queries == the single calls, bitwise (same scan kernel, batch-invariant);
+    # a larger batch runs the matrix-core scan: same rows, scores within f32 rounding
+    toks_of = lambda n: [engine.searcher.bm25.term_ids(["wireless", "mug"]) for _ in range(n)]
     w = FusionWeights(0.5, 0.5, 0.0, 0.0, 0.0)
-    res = engine.searcher.search_batch(Q, toks, 100, 0, w)
-    for b in range(5):
-        one = engine.searcher.search_batch(Q[b:b + 1], toks[:1], 100, 0, w)
-        assert np.array_equal(one.topk_rows()[0], res.topk_rows()[b])
-        assert np.array_equal(one.columns[0], res.columns[b])
+    Q = synth.unit_rows(6, 384, 56)
+    small = engine.searcher.search_batch(Q[:3], toks_of(3), 100, 0, w)
+    big = engine.searcher.search_batch(Q, toks_of(6), 100, 0, w)
+    for b in range(6):
+        one = engine.searcher.search_batch(Q[b:b + 1], toks_of(1), 100, 0, w)
+        if b < 3:
+            assert np.array_equal(one.topk_rows()[0], small.topk_rows()[b])
+            assert np.array_equal(one.columns[0], small.columns[b])
+        assert np.array_equal(one.topk_rows()[0], big.topk_rows()[b])
+        np.testing.assert_allclose(one.columns[0], big.columns[b], atol=TOL, rtol=0)
 
 
 def test_degrade_to_zeros_conventions(world):
