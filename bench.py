@@ -300,7 +300,8 @@ def main():
         # PMC summary for this launch shape is present.
         qpl = min(args.batch, 64) if args.batch > 4 else args.batch   # queries sharing one matrix read
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_scan_b{qpl}_10M.json")
+        chain_tag = "chain_" if (os.environ.get("RR_SCAN_F32_CHAIN") and qpl > 4) else ""
+        pmc = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_scan_{chain_tag}b{qpl}_10M.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
                 m = json.load(f)
@@ -310,9 +311,23 @@ def main():
         bytes_per_launch = n_local * DIM * esz    # algorithmic: the shard's matrix, read once per launch
         avg_ms = total_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-        if qpl > 32:
-            # > 32 queries per read: 2*B flop/byte is past the f32 ridge (~20): the scan is bound by the
-            # f32-input matrix cores (exact f32, v_mfma_f32_16x16x4_f32), not by HBM
+        chain = bool(os.environ.get("RR_SCAN_F32_CHAIN"))
+        if qpl > 4 and not chain:
+            # 5..64 queries per read run on the bf16 matrix cores with exactly-split operands
+            # (rr_dense_x3.hip): 6 (fp32 storage) or 3 (bf16 storage) MFMAs per 32 dims.  Both the HBM
+            # fraction and the matrix-core fraction are reported; the larger one names the bound.
+            terms = 3 if args.dtype == "bf16" else 6
+            pf = terms * 2.0 * n_local * DIM * qpl / (avg_ms * 1e-3) / 1e15 if launches else 0.0
+            hbm_frac, mfma_frac = achieved / HBM_PEAK_GBS, pf / 2.5
+            roof = {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic,
+                    "kernel": f"rr_scan_mfma_x3<{1 if qpl <= 16 else 2 if qpl <= 32 else 4},{args.dtype}>",
+                    "matrix_core_pflops": round(pf, 4), "matrix_core_frac_of_2.5PF": round(mfma_frac, 4)}
+            if mfma_frac > hbm_frac:
+                roof.update({"achieved": round(pf * 1e3, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                             "frac": round(mfma_frac, 4)})
+        elif qpl > 32:
+            # RR_SCAN_F32_CHAIN: f32-input MFMA kernels; > 32 queries per read is past the f32 ridge
             flops = 2.0 * n_local * DIM * qpl
             tf = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
             roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s",

@@ -36,5 +36,8 @@ int rr_dense_chunk_mfma_bf16(rr_index* ix, const float* d_q, int nq, int pool, i
                              float* d_scores, hipStream_t st);
 // l2_normalize of rows [first, first + n) of an fp32 index, in place
 int rr_l2norm_rows_f32(rr_index* ix, int64_t first_row, int64_t n, float eps, hipStream_t st);
+// split-bf16 matrix-core scan (rr_dense_x3.hip): 5..64 queries, either storage dtype
+int rr_dense_chunk_x3(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                      float* d_scores, hipStream_t st);
 // fp32 rows (device, n x dim) -> the index's bf16 matrix rows [first, first + n), optional l2 normalise
 int rr_store_rows_bf16(rr_index* ix, int64_t first_row, int64_t n, float* d_rows_f32, float eps, hipStream_t st);

@@ -903,6 +903,9 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
     RR_HIP_TRY(hipSetDevice(ix->device));
     const bool bf16 = ix->dtype == RR_DTYPE_BF16;
     const bool mfma_ok = ix->dim_pad == 384 && ix->n_rows >= 64;
+    // batches run on the bf16 matrix cores with exactly-split operands (rr_dense_x3.hip);
+    // RR_SCAN_F32_CHAIN=1 selects the f32-input MFMA kernels (scores = pure fmaf chains) instead
+    static const bool f32_chain = getenv("RR_SCAN_F32_CHAIN") != nullptr;
     // measured crossover (10M rows): the per-row-chain VALU scans win up to 4 queries per read
     // (2.4-2.5 ms fp32, 1.3-1.5 ms bf16); from 5 on the matrix-core scan does (2.7-2.9 / 1.8 ms
     // for up to 16 queries, against 3.0 / 2.4 ms for the 8-query VALU scan)
@@ -919,7 +922,8 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
         if (mfma_ok && left > valu_max) {
             // 5..64 queries share one read of the matrix on the matrix cores
             n = left < RR_MFMA_MAXQ ? left : RR_MFMA_MAXQ;
-            if (bf16) rc = rr_dense_chunk_mfma_bf16(ix, q, n, pool, rows, scores, st);
+            if (!f32_chain) rc = rr_dense_chunk_x3(ix, q, n, pool, rows, scores, st);
+            else if (bf16) rc = rr_dense_chunk_mfma_bf16(ix, q, n, pool, rows, scores, st);
             else if (n <= 16) rc = rr_dense_chunk_mfma<1>(ix, q, n, pool, rows, scores, st);
             else if (n <= 32) rc = rr_dense_chunk_mfma<2>(ix, q, n, pool, rows, scores, st);
             else rc = rr_dense_chunk_mfma<4>(ix, q, n, pool, rows, scores, st);

@@ -1,0 +1,250 @@
+// rr_dense_x3.hip -- K1 batched scan on the bf16 matrix cores with split operands.
+//
+// v_mfma_f32_16x16x32_bf16 runs at 16x the rate of the f32-input MFMA.  An fp32 number is the
+// exact sum of three bf16 numbers (8 + 8 + 8 significant bits: x1 = top 16 bits of x,
+// x2 = top 16 bits of x - x1, x3 = x - x1 - x2, every subtraction exact), and a product of two
+// bf16 numbers is exact in fp32.  So  a*q = sum_{i,j} a_i*q_j  with every partial product exact;
+// the three smallest of the nine terms (a2*q3, a3*q2, a3*q3 <= 2^-24 |a*q|, below fp32's own
+// rounding of the product) are dropped:
+//   fp32 matrix  : a1q1 + a1q2 + a2q1 + a2q2 + a1q3 + a3q1   6 MFMAs per 32 dims ( 96 cycles; f32 MFMA: 256)
+//   bf16 matrix  : a q1 + a q2 + a q3 (a is one term, exact)  3 MFMAs per 32 dims ( 48 cycles)
+// Accumulation is the matrix core's fp32 accumulator.  The result is not an fmaf chain any more,
+// but its error (~1e-8 on unit vectors) is that of fp32 rounding itself; the parity bar (rows
+// exact wherever the float64 gap exceeds 4e-7, scores within 1e-5) is the same as for every
+// other scan, and every score is still independent of where the row sits, of the shard and of
+// the grid (one fixed instruction sequence per 16-row M-tile x 16-query tile).
+//
+// Stream structure = rr_scan_mfma_f32: every wave walks its own run of 64-row tiles, fragment
+// loads straight into a VGPR ring (fp32: lane (r, kg) loads the 32 B = 8 floats [32b+8kg, +8)
+// of row r for each of the 12 K-blocks: the four lanes of a row cover one whole 128-B line per
+// instruction pair), inline-asm loads with counted waits, M-tile-major scores.  The queries are
+// split once per launch by rr_split_queries into three bf16 planes that each workgroup copies
+// to LDS, XOR-swizzled in 16-B units (unit u of query q sits at u ^ (q & 15)) so the B-fragment
+// ds_read_b128 is conflict-free.  64 queries x 3 planes = 144 KB: one 512-thread workgroup per
+// CU, 8 waves x 24 KB in flight.
+#include "rr_common.h"
+#include "rr_dense.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define RR_X3_UNITS 48   // 16-byte units (8 bf16) per 384-d query / bf16 row
+
+// queries (slots x 384 fp32) -> planes[3][slots][384] bf16 (truncating split, exact sum)
+__global__ void rr_split_queries(const float* __restrict__ q, unsigned short* __restrict__ planes, int slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots * 384) return;
+    const float x = q[i];
+    const float x1 = __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
+    const float r1 = x - x1;
+    const float x2 = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+    const float x3 = r1 - x2;
+    planes[i] = (unsigned short)(__float_as_uint(x1) >> 16);
+    planes[slots * 384 + i] = (unsigned short)(__float_as_uint(x2) >> 16);
+    planes[2 * slots * 384 + i] = (unsigned short)(__float_as_uint(x3) >> 16);
+}
+
+__device__ __forceinline__ unsigned int rr_pack_hi(float lo_elem, float hi_elem) {
+    // {hi16(hi_elem), hi16(lo_elem)}: element order inside a bf16 pair is low half first
+    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+
+template <int NQT, bool A_BF16>
+__global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_x3(
+    const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ planes,  // [3][16*NQT][48] units
+    float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax) {
+    constexpr int THREADS = NQT == 4 ? 512 : 256;
+    constexpr int QN = 16 * NQT;
+    constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
+    constexpr int RING = A_BF16 ? 12 : 24;            // units a lane holds per M-tile
+    __shared__ u32x4 qs[3 * QN * RR_X3_UNITS];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * QN * RR_X3_UNITS; i += THREADS) {
+        const int u = i % RR_X3_UNITS, pq = i / RR_X3_UNITS;      // pq = plane * QN + query
+        qs[pq * RR_X3_UNITS + (u ^ (pq & 15))] = planes[i];       // QN % 16 == 0: pq & 15 == query & 15
+    }
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int r = lane & 15;
+    const int kg = lane >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * (THREADS / 64) + (tid >> 6);
+    if (wave >= G.n_waves) return;
+    const int64_t t0 = wave * G.tiles_per_wave;
+    const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
+    const int64_t m0 = t0 * 4, m1 = t1 * 4;
+
+    auto row_ptr = [&](int64_t mt) {
+        mt = mt < m1 ? mt : m1 - 1;
+        int64_t row = mt * 16 + r;
+        row = row < G.n_rows ? row : G.n_rows - 1;
+        return mat + row * ROWU + (A_BF16 ? kg : 2 * kg);
+    };
+    // unit j of the ring: fp32: K-block j/2, float4 (2*kg + (j&1)) of it -> byte offset 128*(j/2) + 16*(j&1);
+    //                     bf16: K-block j, unit kg of it                  -> byte offset 64*j
+#define RR_X3_OFF(j) (A_BF16 ? 64 * (j) : 128 * ((j) / 2) + 16 * ((j) & 1))
+#define RR_X3_LOAD(dst, ptr, j) \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(RR_X3_OFF(j)) : "memory")
+    u32x4 a[RING];
+    {
+        const u32x4* p = row_ptr(m0);
+#pragma unroll
+        for (int j = 0; j < RING; ++j) RR_X3_LOAD(a[j], p, j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float tile_max[NQT], gm[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) tile_max[t] = gm[t] = -INFINITY;
+
+#pragma unroll 1
+    for (int64_t mt = m0; mt < m1; ++mt) {
+        const u32x4* pn = row_ptr(mt + 1);
+        f32x4 acc[NQT];
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 12; ++b) {
+            // B fragments first: their LDS latency hides behind the wait for the matrix units and
+            // (fp32) the operand split.  TB query tiles at a time (register budget), the next
+            // group's reads issued before the current group's MFMAs.
+            constexpr int TB = (!A_BF16 && NQT == 4) ? 2 : NQT;
+            const int u = 4 * b + kg;                         // 16-byte unit of the query planes
+            bf16x8 qf[NQT][3];
+#pragma unroll
+            for (int t = 0; t < TB; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    qf[t][pl] = __builtin_bit_cast(bf16x8, qs[(pl * QN + 16 * t + r) * RR_X3_UNITS + (u ^ r)]);
+            bf16x8 a1, a2, a3;
+            if (b % 6 == 0) {
+                // The ring is refilled in two bursts per M-tile (units of K-blocks 0-5 after block 5,
+                // of K-blocks 6-11 after block 11): a burst asks for 6 adjacent 128-B lines of each
+                // of the 16 rows at once, which keeps the DRAM pages open, where one line per row
+                // every K-block does not.  Younger operations than the burst this half needs: the
+                // other half's burst + the score stores in between.
+                constexpr int H = RING / 2;
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(H + NQT) : "memory");
+#pragma unroll
+                for (int j = 0; j < H; ++j) asm volatile("" : "+v"(a[(b / 6) * H + j]));   // uses stay below the wait
+            }
+            if (A_BF16) {
+                a1 = __builtin_bit_cast(bf16x8, a[b]);
+            } else {
+                const f32x4 lo = __builtin_bit_cast(f32x4, a[2 * b]);
+                const f32x4 hi = __builtin_bit_cast(f32x4, a[2 * b + 1]);
+                float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                float h1[8], h2[8], h3[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    h1[e] = __uint_as_float(__float_as_uint(x[e]) & 0xFFFF0000u);
+                    const float r1 = x[e] - h1[e];
+                    h2[e] = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+                    h3[e] = r1 - h2[e];
+                }
+                u32x4 p1, p2, p3;
+                p1.x = rr_pack_hi(h1[0], h1[1]); p1.y = rr_pack_hi(h1[2], h1[3]);
+                p1.z = rr_pack_hi(h1[4], h1[5]); p1.w = rr_pack_hi(h1[6], h1[7]);
+                p2.x = rr_pack_hi(h2[0], h2[1]); p2.y = rr_pack_hi(h2[2], h2[3]);
+                p2.z = rr_pack_hi(h2[4], h2[5]); p2.w = rr_pack_hi(h2[6], h2[7]);
+                p3.x = rr_pack_hi(h3[0], h3[1]); p3.y = rr_pack_hi(h3[2], h3[3]);
+                p3.z = rr_pack_hi(h3[4], h3[5]); p3.w = rr_pack_hi(h3[6], h3[7]);
+                a1 = __builtin_bit_cast(bf16x8, p1);
+                a2 = __builtin_bit_cast(bf16x8, p2);
+                a3 = __builtin_bit_cast(bf16x8, p3);
+            }
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) {
+                if (t % TB == 0 && t + TB < NQT) {            // prefetch the next group of query tiles
+#pragma unroll
+                    for (int t2 = t + TB; t2 < t + 2 * TB; ++t2)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            qf[t2][pl] = __builtin_bit_cast(bf16x8, qs[(pl * QN + 16 * t2 + r) * RR_X3_UNITS + (u ^ r)]);
+                }
+                if (A_BF16) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][0], acc[t], 0, 0, 0);
+                } else {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, qf[t][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, qf[t][1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, qf[t][0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][0], acc[t], 0, 0, 0);
+                }
+            }
+            if (b % 6 == 5) {
+                // this half's units of the next M-tile, as one burst, into the registers just consumed
+                constexpr int H = RING / 2;
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+                    const int unit = (b / 6) * H + j;
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2"
+                                 : "=v"(a[unit]) : "v"(pn), "n"(RR_X3_OFF(unit)), "v"(acc[NQT - 1]) : "memory");
+                }
+            }
+        }
+        // lane (r, kg) holds rows 4*kg .. 4*kg+3 of the M-tile for query 16*t + r
+        const int64_t row0 = mt * 16 + 4 * kg;
+        const bool tile_end = (mt & 3) == 3;
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+            f32x4 v = acc[t];
+            v.x = (row0 + 0 < G.n_rows && v.x == v.x) ? v.x : -INFINITY;   // NaN scores and pad rows rank last
+            v.y = (row0 + 1 < G.n_rows && v.y == v.y) ? v.y : -INFINITY;
+            v.z = (row0 + 2 < G.n_rows && v.z == v.z) ? v.z : -INFINITY;
+            v.w = (row0 + 3 < G.n_rows && v.w == v.w) ? v.w : -INFINITY;
+            *reinterpret_cast<f32x4*>(sims + ((mt * QN + 16 * t + r) * 16 + 4 * kg)) = v;
+            float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+            m4 = fmaxf(m4, __shfl_xor(m4, 16, 64));
+            m4 = fmaxf(m4, __shfl_xor(m4, 32, 64));
+            tile_max[t] = fmaxf(tile_max[t], m4);
+            if (tile_end) {
+                if (kg == 0) gmax[(mt >> 2) * QN + 16 * t + r] = tile_max[t];
+                gm[t] = fmaxf(gm[t], tile_max[t]);
+                tile_max[t] = -INFINITY;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
+    if (kg == 0) {
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) smax[wave * QN + 16 * t + r] = rr_f2key(gm[t]);
+    }
+}
+
+template <int NQT, bool A_BF16>
+static int rr_dense_chunk_x3_t(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                               float* d_scores, hipStream_t st) {
+    constexpr int THREADS = NQT == 4 ? 512 : 256;
+    constexpr int QN = 16 * NQT;
+    static int waves = 0;
+    if (!waves) waves = rr_resident_waves((const void*)rr_scan_mfma_x3<NQT, A_BF16>, THREADS, ix->device);
+    rr_scan_geom G = rr_make_geom(ix, waves / 4);
+    G.qs = QN;
+    // the split query planes live behind the staged queries in the index's query buffer
+    unsigned short* planes = reinterpret_cast<unsigned short*>(ix->d_qplanes);
+    hipLaunchKernelGGL(rr_split_queries, dim3((QN * 384 + 255) / 256), dim3(256), 0, st, d_q, planes, QN);
+    const int slot = rr_scan_events_begin(ix, st);
+    hipLaunchKernelGGL((rr_scan_mfma_x3<NQT, A_BF16>), dim3((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)),
+                       dim3(THREADS), 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
+                       reinterpret_cast<const u32x4*>(planes), ix->d_sims, ix->d_gmax, ix->d_smax);
+    rr_scan_events_end(ix, slot, st);
+    rr_launch_select(ix, G, nq, pool, d_rows, d_scores, st);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_dense_chunk_x3(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                      float* d_scores, hipStream_t st) {
+    const bool b = ix->dtype == RR_DTYPE_BF16;
+    if (nq <= 16)
+        return b ? rr_dense_chunk_x3_t<1, true>(ix, d_q, nq, pool, d_rows, d_scores, st)
+                 : rr_dense_chunk_x3_t<1, false>(ix, d_q, nq, pool, d_rows, d_scores, st);
+    if (nq <= 32)
+        return b ? rr_dense_chunk_x3_t<2, true>(ix, d_q, nq, pool, d_rows, d_scores, st)
+                 : rr_dense_chunk_x3_t<2, false>(ix, d_q, nq, pool, d_rows, d_scores, st);
+    return b ? rr_dense_chunk_x3_t<4, true>(ix, d_q, nq, pool, d_rows, d_scores, st)
+             : rr_dense_chunk_x3_t<4, false>(ix, d_q, nq, pool, d_rows, d_scores, st);
+}
