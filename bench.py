@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=10_000_000)
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--vocab", type=int, default=200_000)
     ap.add_argument("--doc-len", type=int, default=40)

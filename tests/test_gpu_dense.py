@@ -197,3 +197,34 @@ def test_one_million_rows_full_size():
             assert np.array_equal(rows[i], o_rows)
     assert ix.last_scan_ms() > 0
     ix.close()
+
+
+def test_f32_chain_matrix_core_path_in_a_subprocess():
+    """RR_SCAN_F32_CHAIN=1 selects the f32-input MFMA kernels (scores = pure fmaf chains) for
+    batches; the switch is read once per process, so the check runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys; sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np
+from oracle import dense as OD
+from parity import assert_topk_matches
+from review_recommender_amd import synth
+from review_recommender_amd.index import ProductIndex
+for dtype in ("f32", "bf16"):
+    V = synth.unit_rows(20001, 384, 71)
+    Vo = OD.round_to_bf16(V) if dtype == "bf16" else V
+    Q = synth.unit_rows(40, 384, 72)
+    ix = ProductIndex.from_rows(V, dtype=dtype)
+    rows, scores = ix.dense_topk(Q, 150)
+    for i in range(len(Q)):
+        assert_topk_matches(rows[i], scores[i], OD.sims_float64(Vo, Q[i]), 150)
+    r2, s2 = ix.dense_topk(np.concatenate([Q[5:12], Q[:1]]), 150)      # batch-invariant, bitwise
+    assert np.array_equal(r2[-1], rows[0]) and np.array_equal(s2[-1], scores[0])
+print("chain-ok")
+'''
+    env = dict(os.environ, RR_SCAN_F32_CHAIN="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "chain-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
