@@ -191,6 +191,24 @@ int rr_index_gather_meta_dev(rr_index* ix, const int64_t* d_rows, int64_t n,
                              double* d_n_reviews, double* d_avg_stars, double* d_log1p_n,
                              void* stream);
 
+/* ------------------------------------------------------------ best review per candidate */
+
+typedef struct rr_reviews rr_reviews;
+/* Review embeddings of reviews_with_embeddings.parquet (n_reviews x dim fp32, l2-normalised on the
+ * device when normalize_eps > 0 like _best_snippets does, app/app_product_search.py:347-348), grouped
+ * by product: reviews of product row p are h_ids[h_indptr[p] .. h_indptr[p+1]), ascending (file order). */
+int rr_reviews_create(const float* h_emb, int64_t n_reviews, int32_t dim, int64_t n_products,
+                      const int64_t* h_indptr, const int32_t* h_ids, int32_t device,
+                      float normalize_eps, rr_reviews** out);
+int rr_reviews_destroy(rr_reviews* rv);
+/* _best_snippets (app/app_product_search.py:320-370) for the candidates of each query: the review of
+ * product rows[q][c] with the largest dot product with query q (first maximum in file order); reviews
+ * with id > max_review_id are ignored (the max_rows cut of :342-345).  Outputs n_queries x pool:
+ * best score (0 when the product has no review) and best review id (-1 likewise). */
+int rr_reviews_best_dev(rr_reviews* rv, const float* d_queries, int32_t n_queries,
+                        const int64_t* d_rows, int32_t pool, int64_t row_offset, int32_t max_review_id,
+                        float* d_best_score, int32_t* d_best_id, void* stream);
+
 /* Stream helpers for callers that chain *_dev calls. */
 int rr_index_stream(rr_index* ix, void** out_stream);
 int rr_index_synchronize(rr_index* ix);

@@ -59,6 +59,36 @@ def bm25_for_candidates_cli(bm25, bm25_skus: Sequence[str], meta_skus: Sequence[
     return all_scores[top_idx]
 
 
+def best_snippets_oracle(reviews: pd.DataFrame, embeddings: np.ndarray, qvec: np.ndarray,
+                         cand_skus: Sequence[str], max_rows: int, text_cut: int = 600) -> Dict[str, Dict]:
+    """app/app_product_search.py:320-370 (text_cut 600) / app/test.py:181-215 (400) over an
+    in-memory review table instead of the parquet the reference re-reads per query."""
+    try:
+        meta = reviews[["sku", "text", "stars"]]
+        sel = meta["sku"].astype(str).isin(set(cand_skus))
+        sub_meta = meta[sel]
+        if sub_meta.empty:
+            return {}
+        emb = embeddings[sub_meta.index.values]
+        if len(sub_meta) > max_rows:
+            sub_meta = sub_meta.iloc[:max_rows]
+            emb = emb[:max_rows]
+        E = np.stack(list(emb)).astype(np.float32)
+        En = P.l2_normalize(E, axis=1)
+        sims = En @ qvec
+        sub_meta = sub_meta.reset_index(drop=True)
+        sub_meta["__sim"] = sims
+        best = {}
+        for sku, grp in sub_meta.groupby("sku"):
+            j = int(grp["__sim"].values.argmax())
+            row = grp.iloc[j]
+            best[str(sku)] = {"score": float(row["__sim"]), "text": str(row["text"])[:text_cut],
+                              "stars": float(row.get("stars", np.nan))}
+        return best
+    except Exception:          # the reference swallows every failure and returns {} (:366-370)
+        return {}
+
+
 def run_search_oracle(
     *, query: str, qvec: np.ndarray, meta: pd.DataFrame, V: np.ndarray,
     bm25=None, bm25_skus: Optional[Sequence[str]] = None,
@@ -67,11 +97,12 @@ def run_search_oracle(
     w_prior: float = 0.20, w_best: float = 0.10, prior_C: float = 20.0,
     min_reviews: int = 8, gate_penalty: float = 0.5,
     rerank_fn: Optional[Callable[[List[Tuple[str, str]]], np.ndarray]] = None,
-    flavour: str = "app",
+    flavour: str = "app", use_snips: bool = False, max_scan: int = 0,
+    reviews: Optional[Tuple[pd.DataFrame, np.ndarray]] = None,
 ) -> Tuple[pd.DataFrame, Dict, Dict]:
-    """Returns (top-k frame, snips, dbg) like run_search; snippets are out of
-    the hot-path contract (use_snips=False in every benchmark config), so
-    ``_best`` is the all-zero column of app/app_product_search.py:288-294."""
+    """Returns (top-k frame, snips, dbg, full pool frame).  ``reviews`` = (review table,
+    embeddings) stands in for reviews_with_embeddings.parquet; without it (or with
+    use_snips False) ``_best`` is the all-zero column of app/app_product_search.py:288-294."""
     assert flavour in ("app", "cli")
     app = flavour == "app"
     pool = max(k, rerank_k, APP_POOL_FLOOR if app else CLI_POOL_FLOOR)
@@ -114,7 +145,19 @@ def run_search_oracle(
     else:
         cand["_rerank"] = 0.0
 
-    cand["_best"] = np.zeros(len(cand), dtype=np.float32)
+    # app/app_product_search.py:285-294 (CLI: app/test.py:273-289)
+    snips = {}
+    if use_snips and reviews is not None:
+        snips = best_snippets_oracle(reviews[0], reviews[1], qvec, cand["sku"].astype(str).tolist(),
+                                     max_rows=max_scan, text_cut=600 if app else 400)
+    best_contrib = np.zeros(len(cand), dtype=np.float32)
+    if snips:
+        for i, sk in enumerate(cand["sku"].astype(str).tolist()):
+            v = snips.get(sk, {}).get("score")
+            if v is not None:
+                best_contrib[i] = v
+        best_contrib = P.minmax_normalize(best_contrib, empty_passthrough=not app)
+    cand["_best"] = best_contrib
 
     groups = P.build_gate_groups(query)
     gate = [P.calculate_gate_factor(t, groups, penalty=gate_penalty)[0]
@@ -137,7 +180,7 @@ def run_search_oracle(
     out = cand.sort_values("_final", ascending=False).head(k).reset_index(drop=True)
     dbg = {"bm25_active": bm25 is not None, "tokens": P.tokenize_query(query),
            "groups": [list(g) for g in groups], "pool": pool}
-    return out, {}, dbg, cand
+    return out, snips, dbg, cand
 
 
 def cli_rows(frame: pd.DataFrame) -> List[Dict]:

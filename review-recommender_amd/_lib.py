@@ -50,6 +50,9 @@ PROTOTYPES = {
     "rr_fuse_topk_dev": (C.c_int, [c_vp, P(FuseParams), c_i32] + [c_vp] * 9 + [c_vp] * 3 + [c_vp]),
     "rr_fuse_topk": (C.c_int, [c_vp, P(FuseParams), c_i32] + [c_vp] * 9 + [c_vp] * 3),
     "rr_index_gather_meta_dev": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "rr_reviews_create": (C.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_f32, P(c_vp)]),
+    "rr_reviews_destroy": (C.c_int, [c_vp]),
+    "rr_reviews_best_dev": (C.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "rr_index_stream": (C.c_int, [c_vp, P(c_vp)]),
     "rr_index_synchronize": (C.c_int, [c_vp]),
 }

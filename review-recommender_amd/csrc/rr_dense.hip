@@ -988,7 +988,10 @@ extern "C" int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_que
                "rr_dense_topk: bf16 storage is built for dim 384 only");
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
-    hipStream_t st = ix->stream;
+    // The scan scratch of the handle is shared with rr_dense_topk_dev callers, who run on the
+    // device's default stream unless they say otherwise: use that stream here too so two host
+    // threads (one on each entry point) stay ordered on the scratch.
+    hipStream_t st = nullptr;
     const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);   // kernels read whole query tiles
     RR_HIP_TRY(hipMemsetAsync(ix->d_q, 0, sizeof(float) * (size_t)slots * ix->dim_pad, st));
     RR_HIP_TRY(hipMemcpy2DAsync(ix->d_q, sizeof(float) * ix->dim_pad, h_queries,

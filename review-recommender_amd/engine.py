@@ -58,6 +58,8 @@ class BatchResult:
     bm25_raw: np.ndarray       # (B, pool) float32 raw BM25 scores
     pool: int
     k: int
+    best_ids: Optional[np.ndarray] = None    # (B, pool) best review id per candidate, -1 = none
+    best_raw: Optional[np.ndarray] = None    # (B, pool) its raw score
 
     def topk_rows(self) -> np.ndarray:
         return np.take_along_axis(self.pool_rows, self.order.astype(np.int64), axis=1)
@@ -178,7 +180,7 @@ class HybridSearcher:
                      pool_floor: int = APP_POOL_FLOOR,
                      gate_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None,
                      rerank_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None,
-                     bm25_mode: str = "forward") -> BatchResult:
+                     bm25_mode: str = "forward", reviews=None, max_scan: int = 0) -> BatchResult:
         """qvecs (B, dim) float32; term_id_lists: per-query BM25 token ids (None = no BM25).
         gate_fn / rerank_fn map the (B, pool) pool rows to (B, pool) float32 gate factors /
         (B, rr_k) raw reranker scores; they run on the host between K2 and K3."""
@@ -200,9 +202,22 @@ class HybridSearcher:
             rows, dense = self.dense_pool(q_dev, pool)
             tl = term_id_lists if term_id_lists is not None else [[] for _ in range(B)]
             bm = self.bm25_at(tl, rows, bm25_mode)
-            gate = rerank = None
-            if gate_fn is not None or (rerank_fn is not None and rr_k > 0):
+            gate = rerank = best = None
+            best_ids = None
+            rows_h = None
+            if reviews is not None:
+                # best review per candidate (csrc/rr_reviews.hip); the max_rows cut needs the rows on the host
                 rows_h = rows.cpu().numpy()
+                best = torch.zeros((B, pool), dtype=torch.float32, device=self.device)
+                best_ids = torch.full((B, pool), -1, dtype=torch.int32, device=self.device)
+                for b in range(B):      # the cut differs per query
+                    cut = reviews.cut_for(rows_h[b] - self.index.row_offset, max_scan)
+                    _lib.check(self.lib.rr_reviews_best_dev(
+                        reviews.handle, C.c_void_p(q_dev[b:b + 1].data_ptr()), 1, C.c_void_p(rows[b:b + 1].data_ptr()),
+                        pool, self.index.row_offset, cut, C.c_void_p(best[b:b + 1].data_ptr()),
+                        C.c_void_p(best_ids[b:b + 1].data_ptr()), self._stream()), "rr_reviews_best_dev")
+            if gate_fn is not None or (rerank_fn is not None and rr_k > 0):
+                rows_h = rows.cpu().numpy() if rows_h is None else rows_h
                 if gate_fn is not None:
                     g = np.ascontiguousarray(gate_fn(rows_h), dtype=np.float32)
                     gate = torch.from_numpy(g).to(self.device)
@@ -211,9 +226,11 @@ class HybridSearcher:
                     r[:, :rr_k] = np.asarray(rerank_fn(rows_h[:, :rr_k]), dtype=np.float32)
                     rerank = torch.from_numpy(r).to(self.device)
             params = self.make_params(w, k_eff, pool, pool, rr_k)
-            out_rows, cols, order = self.fuse(params, B, rows, dense, bm, None, rerank, None, gate)
+            out_rows, cols, order = self.fuse(params, B, rows, dense, bm, None, rerank, best, gate)
             res = BatchResult(out_rows.cpu().numpy(), cols.cpu().numpy(), order.cpu().numpy(),
                               dense.cpu().numpy(), bm.cpu().numpy(), pool, k_eff)
+            if best_ids is not None:
+                res.best_ids, res.best_raw = best_ids.cpu().numpy(), best.cpu().numpy()
         return res
 
 
@@ -229,7 +246,7 @@ class SearchEngine:
 
     def __init__(self, meta: pd.DataFrame, embeddings: np.ndarray, bm25_blob: Optional[dict] = None,
                  *, encoder=None, cross_encoder=None, device: int = 0, normalize: bool = True,
-                 flavour: str = "app", dtype: str = "f32"):
+                 flavour: str = "app", dtype: str = "f32", reviews: Optional[Tuple] = None):
         if flavour not in ("app", "cli"):
             raise ValueError("flavour must be 'app' or 'cli'")
         if len(meta) != embeddings.shape[0]:
@@ -255,6 +272,11 @@ class SearchEngine:
             aligned = self.bm25_corpus.select(self._align_bm25([str(s) for s in bm25_blob["skus"]]))
             bm25_index = aligned.to_device(device)
         self.searcher = HybridSearcher(self.index, bm25_index)
+        # reviews = (frame with sku/text/stars, (n_reviews, dim) embeddings): reviews_with_embeddings.parquet
+        self.reviews = None
+        if reviews is not None:
+            from .reviews import ReviewIndex
+            self.reviews = ReviewIndex(reviews[0], reviews[1], self.meta["sku"].astype(str).tolist(), device=device)
 
     @classmethod
     def from_artifacts(cls, data_dir, **kw) -> "SearchEngine":
@@ -321,8 +343,10 @@ class SearchEngine:
                    ) -> Tuple[pd.DataFrame, Dict, Dict]:
         """Same positional / keyword signature and return triple as the reference's
         run_search (app/app_product_search.py:245-248, 312-317); ``qvec`` lets a caller
-        supply the query embedding when no encoder is loaded.  Snippets (use_snips) are
-        outside the hot-path contract: ``snips`` is {} and ``_best`` is zeros."""
+        supply the query embedding when no encoder is loaded.  With ``use_snips`` and a review
+        index (``reviews=`` of the constructor) ``snips`` and ``_best`` are filled like
+        _best_snippets does (app/app_product_search.py:285-294, 320-370); otherwise ``snips`` is {}
+        and ``_best`` zeros, as in the reference when the review file is absent."""
         app = self.flavour == "app"
         qv = self.encode(query) if qvec is None else np.asarray(qvec, dtype=np.float32)
         toks = text.tokenize_query(query)
@@ -336,12 +360,17 @@ class SearchEngine:
             qv[None, :], term_ids, k, rerank_k, w,
             pool_floor=APP_POOL_FLOOR if app else CLI_POOL_FLOOR,
             gate_fn=gate_fn if groups else None,
-            rerank_fn=self._rerank_fn(query) if rerank_k > 0 else None)
+            rerank_fn=self._rerank_fn(query) if rerank_k > 0 else None,
+            reviews=self.reviews if use_snips else None, max_scan=max_scan)
         frame = self._frame(res, 0)
+        snips = {}
+        if res.best_ids is not None:
+            skus = self.meta["sku"].astype(str).iloc[res.pool_rows[0]].tolist()
+            snips = self.reviews.snippets(skus, res.best_ids[0], res.best_raw[0], 600 if app else 400)
         dbg = {"bm25_active": self.searcher.bm25 is not None, "tokens": toks,
                "groups": [list(g) for g in groups], "pool": max(k, rerank_k,
                                                               APP_POOL_FLOOR if app else CLI_POOL_FLOOR)}
-        return frame, {}, dbg
+        return frame, snips, dbg
 
     def _frame(self, res: BatchResult, b: int) -> pd.DataFrame:
         top = res.order[b].astype(np.int64)

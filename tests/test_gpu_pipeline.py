@@ -231,3 +231,30 @@ def test_missing_and_duplicate_skus_in_the_bm25_blob(world):
                                   qvec=qv)
     assert got["sku"].tolist() == want["sku"].tolist()
     np.testing.assert_allclose(got["_final"].values, want["_final"].values, atol=TOL, rtol=0)
+
+
+def test_one_engine_shared_by_threads(world):
+    """Streamlit runs each session in its own thread and shares cached objects
+    (app/app_product_search.py:53,71,119): concurrent run_search calls on one engine must give the
+    answers the sequential calls give."""
+    import threading
+    engine = SearchEngine(world["meta"], world["V"], world["blob"], normalize=False)
+    Q = synth.unit_rows(12, 384, 77)
+    queries = [QUERIES[i % len(QUERIES)] for i in range(12)]
+    cfg = CONFIGS["hybrid"]
+
+    def call(i):
+        f, _, _ = engine.run_search(queries[i], cfg["k"], 0, cfg["w_dense"], cfg["w_bm25"], 0.0, cfg["w_prior"], 0.0,
+                                    20.0, False, 0, cfg["min_reviews"], cfg["gate_penalty"], qvec=Q[i])
+        return f["sku"].tolist(), f["_final"].values.copy()
+
+    want = [call(i) for i in range(12)]
+    got = [None] * 12
+    def worker(i):
+        got[i] = call(i)
+    for rep in range(3):
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(12)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        for i in range(12):
+            assert got[i][0] == want[i][0] and np.array_equal(got[i][1], want[i][1])
