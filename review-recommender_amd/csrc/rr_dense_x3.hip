@@ -15,9 +15,10 @@
 // the grid (one fixed instruction sequence per 16-row M-tile x 16-query tile).
 //
 // Stream structure = rr_scan_mfma_f32: every wave walks its own run of 64-row tiles, fragment
-// loads straight into a VGPR ring (fp32: lane (r, kg) loads the 32 B = 8 floats [32b+8kg, +8)
-// of row r for each of the 12 K-blocks: the four lanes of a row cover one whole 128-B line per
-// instruction pair), inline-asm loads with counted waits, M-tile-major scores.  The queries are
+// loads straight into a VGPR ring (fp32: for each of the 12 K-blocks lane (r, kg) loads floats
+// [32b+4kg, +4) and [32b+16+4kg, +4) of row r, so the four lanes of a row read 64 contiguous bytes
+// per instruction; the query planes are permuted to the same k order), inline-asm loads with
+// counted waits, M-tile-major scores.  The queries are
 // split once per launch by rr_split_queries into three bf16 planes that each workgroup copies
 // to LDS, XOR-swizzled in 16-B units (unit u of query q sits at u ^ (q & 15)) so the B-fragment
 // ds_read_b128 is conflict-free.  64 queries x 3 planes = 144 KB: one 512-thread workgroup per
@@ -30,11 +31,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define RR_X3_UNITS 48   // 16-byte units (8 bf16) per 384-d query / bf16 row
 
-// queries (slots x 384 fp32) -> planes[3][slots][384] bf16 (truncating split, exact sum)
-__global__ void rr_split_queries(const float* __restrict__ q, unsigned short* __restrict__ planes, int slots) {
+// queries (slots x 384 fp32) -> planes[3][slots][384] bf16 (truncating split, exact sum).
+// `interleave`: inside every 32-dim K-block, MFMA k-slot (kg, j) stands for dim 4*kg + j (j < 4) or
+// 16 + 4*kg + (j - 4): the order in which an fp32-matrix lane holds its two 16-byte loads when the
+// four lanes of a row read 64 contiguous bytes per instruction (see RR_X3_OFF).
+__global__ void rr_split_queries(const float* __restrict__ q, unsigned short* __restrict__ planes, int slots,
+                                 int interleave) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= slots * 384) return;
-    const float x = q[i];
+    int src = i;
+    if (interleave) {
+        const int e = i & 31, kg = e >> 3, j = e & 7;
+        src = (i & ~31) + (j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4));
+    }
+    const float x = q[src];
     const float x1 = __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
     const float r1 = x - x1;
     const float x2 = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
@@ -74,15 +84,32 @@ __global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_x3(
     const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
     const int64_t m0 = t0 * 4, m1 = t1 * 4;
 
+    // LOAD mapping: lane L reads row (L >> 2), 16-byte piece (L & 3) of each 64-byte group: four
+    // ADJACENT lanes cover 64 contiguous bytes, which the vector L1 looks up once; with the MFMA
+    // mapping (row = lane & 15) adjacent lanes are 16 different rows = 64 lookups of 16 B per
+    // instruction, and the L1 tag rate, not HBM, paced the scan (TA_ADDR_STALLED_BY_TC 80 % of the
+    // time).  The registers are moved to the MFMA mapping (lane r + 16*kg <- lane 4*r + kg) with
+    // ds_bpermute after they land.
+    const int lrow = lane >> 2, lkg = lane & 3;
+    const int bperm_src = 4 * (4 * r + kg);          // byte address of the source lane for ds_bpermute
     auto row_ptr = [&](int64_t mt) {
         mt = mt < m1 ? mt : m1 - 1;
-        int64_t row = mt * 16 + r;
+        int64_t row = mt * 16 + lrow;
         row = row < G.n_rows ? row : G.n_rows - 1;
-        return mat + row * ROWU + (A_BF16 ? kg : 2 * kg);
+        return mat + row * ROWU + lkg;
     };
-    // unit j of the ring: fp32: K-block j/2, float4 (2*kg + (j&1)) of it -> byte offset 128*(j/2) + 16*(j&1);
-    //                     bf16: K-block j, unit kg of it                  -> byte offset 64*j
-#define RR_X3_OFF(j) (A_BF16 ? 64 * (j) : 128 * ((j) / 2) + 16 * ((j) & 1))
+    auto to_mfma_lanes = [&](u32x4 v) {
+        u32x4 o;
+        o.x = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_src, (int)v.x);
+        o.y = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_src, (int)v.y);
+        o.z = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_src, (int)v.z);
+        o.w = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_src, (int)v.w);
+        return o;
+    };
+    // unit j of the ring: fp32: K-block j/2, float4 (kg + 4*(j&1)) of it: the four lanes of a row read
+    //                           64 contiguous bytes (half a line) per instruction -> offset 128*(j/2) + 64*(j&1);
+    //                     bf16: K-block j, unit kg of it (64 contiguous bytes)    -> offset 64*j
+#define RR_X3_OFF(j) (A_BF16 ? 64 * (j) : 128 * ((j) / 2) + 64 * ((j) & 1))
 #define RR_X3_LOAD(dst, ptr, j) \
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(RR_X3_OFF(j)) : "memory")
     u32x4 a[RING];
@@ -128,10 +155,10 @@ __global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_x3(
                 for (int j = 0; j < H; ++j) asm volatile("" : "+v"(a[(b / 6) * H + j]));   // uses stay below the wait
             }
             if (A_BF16) {
-                a1 = __builtin_bit_cast(bf16x8, a[b]);
+                a1 = __builtin_bit_cast(bf16x8, to_mfma_lanes(a[b]));
             } else {
-                const f32x4 lo = __builtin_bit_cast(f32x4, a[2 * b]);
-                const f32x4 hi = __builtin_bit_cast(f32x4, a[2 * b + 1]);
+                const f32x4 lo = __builtin_bit_cast(f32x4, to_mfma_lanes(a[2 * b]));
+                const f32x4 hi = __builtin_bit_cast(f32x4, to_mfma_lanes(a[2 * b + 1]));
                 float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 float h1[8], h2[8], h3[8];
 #pragma unroll
@@ -225,7 +252,8 @@ static int rr_dense_chunk_x3_t(rr_index* ix, const float* d_q, int nq, int pool,
     G.qs = QN;
     // the split query planes live behind the staged queries in the index's query buffer
     unsigned short* planes = reinterpret_cast<unsigned short*>(ix->d_qplanes);
-    hipLaunchKernelGGL(rr_split_queries, dim3((QN * 384 + 255) / 256), dim3(256), 0, st, d_q, planes, QN);
+    hipLaunchKernelGGL(rr_split_queries, dim3((QN * 384 + 255) / 256), dim3(256), 0, st, d_q, planes, QN,
+                       A_BF16 ? 0 : 1);
     const int slot = rr_scan_events_begin(ix, st);
     hipLaunchKernelGGL((rr_scan_mfma_x3<NQT, A_BF16>), dim3((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)),
                        dim3(THREADS), 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,

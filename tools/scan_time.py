@@ -1,5 +1,5 @@
 """Times the dense scan alone (dev tool): python tools/scan_time.py <rows> <batch> [reps]"""
-import sys, time; sys.path.insert(0, '.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from review_recommender_amd.index import ProductIndex
 n, b = int(sys.argv[1]), int(sys.argv[2]); reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
