@@ -97,10 +97,17 @@ int rr_index_last_scan_ms(rr_index* ix, float* out_ms);
  * Drains the pairs recorded since the last call: total ms and launch count. */
 int rr_index_scan_stats(rr_index* ix, double* out_total_ms, int64_t* out_launches);
 /* Path taken by the last top-pool selection for its first query: out4 = {1 if the
- * LDS-resident 3-level path finished (0: generic radix fallback), groups opened, tiles
+ * LDS-resident 3-level path finished (2: the two-pass rescoring path; 0: generic radix fallback), groups opened, tiles
  * opened, candidate rows}, out16[4..10] = shader-clock cycles of the selection's phases.
  * Diagnostic: lets tests assert the fast path is the one running. */
 int rr_index_select_trace(rr_index* ix, int32_t* out16);
+/* Diagnostic switch of the batched (5..64 query) scan.  RR_SCAN_MODE_DEFAULT: the scan keeps only
+ * M-tile maxima and the candidate M-tiles are rescored (select trace out16[0] == 2), with the
+ * stored-score pass as per-query fallback.  RR_SCAN_MODE_STORED: always the single pass that
+ * stores every score.  Both return identical rows and scores; tests compare them. */
+#define RR_SCAN_MODE_DEFAULT 0
+#define RR_SCAN_MODE_STORED 1
+int rr_index_set_scan_mode(rr_index* ix, int32_t mode);
 
 /* ------------------------------------------------------------ K2 BM25 */
 

@@ -63,6 +63,7 @@ extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim
     }
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sel_trace, sizeof(int32_t) * 16 * 64);
     if (e == hipSuccess) e = hipMalloc(&ix->d_qplanes, (size_t)3 * 64 * 384 * 2);
+    if (e == hipSuccess) e = hipMalloc(&ix->d_x3, rr_x3_scratch_bytes());
     if (e == hipSuccess) e = hipMalloc(&ix->d_q, sizeof(float) * (size_t)RR_MAX_BATCH * ix->dim_pad);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_rows_out, sizeof(int64_t) * (size_t)RR_MAX_BATCH * RR_MAX_POOL);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_scores_out, sizeof(float) * (size_t)RR_MAX_BATCH * RR_MAX_POOL);
@@ -180,7 +181,7 @@ extern "C" int rr_index_destroy(rr_index* ix) {
     if (ix->stream) hipStreamSynchronize(ix->stream);
     if (ix->d_matrix && ix->owns_matrix) hipFree(ix->d_matrix);
     hipFree(ix->d_n_reviews); hipFree(ix->d_avg_stars); hipFree(ix->d_log1p_n);
-    hipFree(ix->d_sims); hipFree(ix->d_gmax); hipFree(ix->d_smax); hipFree(ix->d_sel_trace); hipFree(ix->d_qplanes); hipFree(ix->d_q);
+    hipFree(ix->d_sims); hipFree(ix->d_gmax); hipFree(ix->d_smax); hipFree(ix->d_sel_trace); hipFree(ix->d_qplanes); hipFree(ix->d_x3); hipFree(ix->d_q);
     hipFree(ix->d_rows_out); hipFree(ix->d_scores_out);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);

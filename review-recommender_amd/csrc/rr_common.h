@@ -52,6 +52,8 @@ struct rr_index {
     uint32_t* d_smax = nullptr;  // [qcap][n_super] ordered keys of super-tile maxima
     int32_t scratch_q = 0;
     float* d_q = nullptr;        // staged queries [RR_MAX_BATCH][dim_pad]
+    int32_t scan_mode = 0;       // RR_SCAN_MODE_* (rr_index_set_scan_mode)
+    void* d_x3 = nullptr;        // two-pass selection scratch of the split-operand scan (rr_x3_scratch)
     void* d_qplanes = nullptr;   // [3][64][384] bf16: one launch's queries split in three bf16 terms
     int64_t* d_rows_out = nullptr;  // host-API staging [RR_MAX_BATCH][RR_MAX_POOL]
     float* d_scores_out = nullptr;

@@ -25,8 +25,23 @@ rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks);
 int rr_scan_events_begin(rr_index* ix, hipStream_t st);
 void rr_scan_events_end(rr_index* ix, int slot, hipStream_t st);
 // Exact top-pool of `nq` queries from the three score levels a scan left in the index scratch.
+// `only_if` (device, one flag per query, may be null): queries whose flag is 0 are skipped.
 void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
-                      float* d_scores, hipStream_t st);
+                      float* d_scores, hipStream_t st, const int32_t* only_if = nullptr);
+// Two-pass selection of the split-operand scan (see rr_select_mtiles in rr_dense.hip).
+#define RR_X3_MCAP 2048          // M-tiles (16 rows) one query may ask to have rescored
+struct rr_x3_scratch {
+    uint32_t* mtiles;            // [RR_MFMA_MAXQ][RR_X3_MCAP] M-tile ids to rescore
+    int32_t* count;              // [RR_MFMA_MAXQ] how many
+    uint32_t* tau;               // [RR_MFMA_MAXQ] key threshold of the query
+    int32_t* fb;                 // [RR_MFMA_MAXQ] 1 = the query needs the stored-score fallback
+    float* sc;                   // [RR_MFMA_MAXQ][RR_X3_MCAP][16] rescored rows
+};
+rr_x3_scratch rr_x3_scratch_of(const rr_index* ix);
+size_t rr_x3_scratch_bytes();
+void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st);
+void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
+                               float* d_scores, hipStream_t st);
 // Waves a kernel can keep resident on the device (occupancy x CUs x waves per workgroup).
 int rr_resident_waves(const void* kernel, int threads, int device);
 // bf16-storage scans (rr_dense_bf16.hip): up to 8 (VALU) or 9..64 (matrix cores) queries.

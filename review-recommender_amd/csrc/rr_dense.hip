@@ -584,6 +584,42 @@ __device__ void rr_rank_sort_desc(const uint64_t* keys, int n, uint64_t* out) {
     __syncthreads();
 }
 
+// tau = the pool-th largest group maximum (1 = "everything" when there are no more than `pool`
+// groups), and the groups that reach it into list2 (count in counters[0], which may exceed
+// RR_SEL_LCAP: the caller checks).  All threads of the 1024-thread workgroup call this.
+template <typename GroupKeyAt>
+__device__ uint32_t rr_sel_open_groups(GroupKeyAt group_key_at, int ng, int pool, uint32_t (*cnt)[3][16],
+                                       int& phase, uint32_t* counters, uint32_t* list2) {
+    const int tid = threadIdx.x;
+    uint32_t r[RR_SEL_RK];
+    int n_mine = 0;
+#pragma unroll
+    for (int j = 0; j < RR_SEL_RK; ++j) {
+        const int i = tid + j * RR_SEL_THREADS;
+        r[j] = i < ng ? group_key_at(i) : 0u;
+        n_mine += i < ng ? 1 : 0;
+    }
+    // 7 two-bit steps below the highest differing bit: tau is within 2^-14 of the spread of
+    // the group maxima below the exact pool-th largest, i.e. it opens a handful more groups
+    uint32_t tau = 1u;
+    if (ng > pool) {
+        if (ng <= 1 * RR_SEL_THREADS) tau = rr_kth_largest_reg<1>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
+        else if (ng <= 2 * RR_SEL_THREADS) tau = rr_kth_largest_reg<2>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
+        else if (ng <= 4 * RR_SEL_THREADS) tau = rr_kth_largest_reg<4>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
+        else tau = rr_kth_largest_reg<8>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
+    }
+    if (tau == 0u) tau = 1u;                           // key 0 marks padding, never a score
+#pragma unroll
+    for (int j = 0; j < RR_SEL_RK; ++j) {
+        if (j < n_mine && r[j] >= tau) {
+            const uint32_t slot = atomicAdd(&counters[0], 1u);
+            if (slot < RR_SEL_LCAP) list2[slot] = (uint32_t)(tid + j * RR_SEL_THREADS);
+        }
+    }
+    __syncthreads();
+    return tau;
+}
+
 // rr_select: one 1024-thread workgroup per query; exact top-pool by (score desc, row asc).
 //
 // The scan leaves three levels behind: the score of every row, the maximum of every 64-row
@@ -598,7 +634,9 @@ __device__ void rr_rank_sort_desc(const uint64_t* keys, int n, uint64_t* out) {
 __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
     rr_scan_geom G, const float* __restrict__ sims, const float* __restrict__ gmax,
     const uint32_t* __restrict__ smax, int pool, int64_t row_offset,
-    int64_t* __restrict__ out_rows, float* __restrict__ out_scores, int32_t* __restrict__ dbg) {
+    int64_t* __restrict__ out_rows, float* __restrict__ out_scores, int32_t* __restrict__ dbg,
+    const int32_t* __restrict__ only_if) {
+    if (only_if && !only_if[blockIdx.x]) return;      // fallback launch: this query was served already
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t cnt[2][3][16];
@@ -634,34 +672,9 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
     __syncthreads();
 
     if (fast) {
-        // ---- tau: pool-th largest group maximum (every non-empty group if there are few)
-        uint32_t r[RR_SEL_RK];
-        int n_mine = 0;
-#pragma unroll
-        for (int j = 0; j < RR_SEL_RK; ++j) {
-            const int i = tid + j * RR_SEL_THREADS;
-            r[j] = i < ng ? group_key_at(i) : 0u;
-            n_mine += i < ng ? 1 : 0;
-        }
-        // 7 two-bit steps below the highest differing bit: tau is within 2^-14 of the spread of
-        // the group maxima below the exact pool-th largest, i.e. it opens a handful more groups
-        uint32_t tau = 1u;
-        if (ng > pool) {
-            if (ng <= 1 * RR_SEL_THREADS) tau = rr_kth_largest_reg<1>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
-            else if (ng <= 2 * RR_SEL_THREADS) tau = rr_kth_largest_reg<2>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
-            else if (ng <= 4 * RR_SEL_THREADS) tau = rr_kth_largest_reg<4>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
-            else tau = rr_kth_largest_reg<8>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
-        }
-        if (tau == 0u) tau = 1u;                           // key 0 marks padding, never a score
-        RR_STAMP();   // 1: tau found
-#pragma unroll
-        for (int j = 0; j < RR_SEL_RK; ++j) {
-            if (j < n_mine && r[j] >= tau) {
-                const uint32_t slot = atomicAdd(&counters[0], 1u);
-                if (slot < RR_SEL_LCAP) list2[slot] = (uint32_t)(tid + j * RR_SEL_THREADS);
-            }
-        }
-        __syncthreads();
+        // ---- tau: pool-th largest group maximum; the groups that reach it
+        const uint32_t tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2);
+        RR_STAMP();   // 1: tau found, groups listed
         if (counters[0] > RR_SEL_LCAP) fast = false;
 
         // ---- tiles of the opened groups whose maximum reaches tau
@@ -731,6 +744,149 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
     }
 }
 
+// ------------------------------------------------------------------ two-pass selection (split-operand scan)
+// The split-operand scan (rr_dense_x3.hip) keeps no per-row scores: only the maximum of every
+// 16-row M-tile ([tile][query][4]) and of every wave's run.  Selection therefore runs in two steps
+// around rr_rescore_x3:
+//   rr_select_mtiles   tau from the group maxima, then the M-tiles whose maximum reaches tau
+//                      (~pool + ties) -> x3 scratch (ids, count, tau)
+//   rr_rescore_x3      recomputes the 16 scores of each listed M-tile, bit for bit as the scan did
+//   rr_select_rescored rows with score >= tau among them, ordered by (score desc, row asc)
+// A query whose lists outgrow the scratch raises its flag in `fb`; the caller then re-runs the
+// storing scan + rr_select for the flagged queries (both return at once when no flag is up).
+__global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
+    rr_scan_geom G, const float* __restrict__ mmax, const uint32_t* __restrict__ smax, int pool,
+    uint32_t* __restrict__ out_mtiles, int32_t* __restrict__ out_count, uint32_t* __restrict__ out_tau,
+    int32_t* __restrict__ fb, int32_t* __restrict__ dbg) {
+    __shared__ uint32_t cnt[2][3][16];
+    __shared__ uint32_t counters[4];
+    __shared__ uint32_t list2[RR_SEL_LCAP];
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    const int QS = G.qs;
+    auto group_key_at = [&](int i) -> uint32_t { return smax[(int64_t)i * QS + q]; };
+    const int ng = G.n_waves;
+    int phase = 0;
+    if (tid < 4) counters[tid] = 0;
+    __syncthreads();
+    bool ok = ng <= RR_SEL_RK * RR_SEL_THREADS && ng > pool;   // few groups = a small matrix: take the stored path
+    uint32_t tau = 1u;
+    if (ok) {
+        tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2);
+        if (counters[0] > RR_SEL_LCAP) ok = false;
+    }
+    if (ok) {
+        const int C = (int)G.tiles_per_wave;
+        const int64_t n2 = (int64_t)counters[0] * C;
+        const f32x4* mm4 = reinterpret_cast<const f32x4*>(mmax);
+        for (int64_t i = tid; i < n2; i += RR_SEL_THREADS) {
+            const int64_t t = (int64_t)list2[i / C] * C + (i % C);
+            if (t >= G.n_tiles) continue;
+            const f32x4 m = mm4[t * QS + q];
+            const float v[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                if (rr_f2key(v[sub]) >= tau) {
+                    const uint32_t slot = atomicAdd(&counters[1], 1u);
+                    if (slot < RR_X3_MCAP) out_mtiles[(int64_t)q * RR_X3_MCAP + slot] = (uint32_t)(t * 4 + sub);
+                }
+            }
+        }
+        __syncthreads();
+        if (counters[1] > RR_X3_MCAP) ok = false;
+    }
+    if (tid == 0) {
+        out_count[q] = ok ? (int32_t)counters[1] : 0;
+        out_tau[q] = tau;
+        fb[q] = ok ? 0 : 1;
+        dbg[q * 16 + 0] = ok ? 2 : 0;                 // 2 = two-pass (may still fall back in the second step)
+        dbg[q * 16 + 1] = (int32_t)counters[0];
+        dbg[q * 16 + 2] = (int32_t)counters[1];
+        dbg[q * 16 + 3] = 0;
+        for (int i = 4; i < 16; ++i) dbg[q * 16 + i] = -1;
+    }
+}
+
+__global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
+    rr_scan_geom G, const uint32_t* __restrict__ mtiles, const int32_t* __restrict__ count,
+    const uint32_t* __restrict__ tau_of, const float* __restrict__ sc, int pool, int64_t row_offset,
+    int64_t* __restrict__ out_rows, float* __restrict__ out_scores, int32_t* __restrict__ fb,
+    int32_t* __restrict__ dbg) {
+    __shared__ uint32_t counters[2];
+    __shared__ uint64_t cand[RR_SEL_CCAP];
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x;
+    if (fb[q]) return;
+    if (tid < 2) counters[tid] = 0;
+    __syncthreads();
+    const uint32_t tau = tau_of[q];
+    const int n1 = count[q] * 16;
+    for (int i = tid; i < n1; i += RR_SEL_THREADS) {
+        const int64_t at = (int64_t)q * RR_X3_MCAP + (i >> 4);
+        const uint32_t row = mtiles[at] * 16u + (uint32_t)(i & 15);
+        if ((int64_t)row < G.n_rows) {
+            const uint32_t key = rr_f2key(sc[at * 16 + (i & 15)]);
+            if (key >= tau) {
+                const uint32_t slot = atomicAdd(&counters[0], 1u);
+                if (slot < RR_SEL_CCAP / 2) cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - row);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_cand = counters[0];
+    if (tid == 0) dbg[q * 16 + 3] = (int32_t)n_cand;
+    if (n_cand > RR_SEL_CCAP / 2 || n_cand < (uint32_t)pool) {    // massive ties at the cut
+        if (tid == 0) {
+            fb[q] = 1;
+            dbg[q * 16 + 0] = 0;
+        }
+        return;
+    }
+    if (n_cand <= RR_SEL_THREADS) {
+        rr_rank_sort_desc(cand, (int)n_cand, cand + RR_SEL_CCAP / 2);
+        for (int i = tid; i < pool; i += RR_SEL_THREADS) cand[i] = cand[RR_SEL_CCAP / 2 + i];
+        __syncthreads();
+    } else {
+        int n_sort = 1;
+        while (n_sort < (int)n_cand) n_sort <<= 1;
+        for (int i = tid; i < n_sort; i += RR_SEL_THREADS)
+            if (i >= (int)n_cand) cand[i] = 0;
+        rr_bitonic_desc(cand, n_sort);
+    }
+    for (int i = tid; i < pool; i += RR_SEL_THREADS) {
+        const uint64_t key = cand[i];
+        const uint32_t row = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+        out_rows[(int64_t)q * pool + i] = (int64_t)row + row_offset;
+        out_scores[(int64_t)q * pool + i] = rr_key2f((uint32_t)(key >> 32));
+    }
+}
+
+rr_x3_scratch rr_x3_scratch_of(const rr_index* ix) {
+    rr_x3_scratch s;
+    char* p = static_cast<char*>(ix->d_x3);
+    s.mtiles = reinterpret_cast<uint32_t*>(p);  p += sizeof(uint32_t) * RR_MFMA_MAXQ * RR_X3_MCAP;
+    s.count = reinterpret_cast<int32_t*>(p);    p += sizeof(int32_t) * RR_MFMA_MAXQ;
+    s.tau = reinterpret_cast<uint32_t*>(p);     p += sizeof(uint32_t) * RR_MFMA_MAXQ;
+    s.fb = reinterpret_cast<int32_t*>(p);       p += sizeof(int32_t) * RR_MFMA_MAXQ;
+    s.sc = reinterpret_cast<float*>(p);
+    return s;
+}
+size_t rr_x3_scratch_bytes() {
+    return sizeof(uint32_t) * RR_MFMA_MAXQ * RR_X3_MCAP + 3 * sizeof(int32_t) * RR_MFMA_MAXQ +
+           sizeof(float) * (size_t)RR_MFMA_MAXQ * RR_X3_MCAP * 16;
+}
+void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st) {
+    const rr_x3_scratch s = rr_x3_scratch_of(ix);
+    hipLaunchKernelGGL(rr_select_mtiles, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_gmax, ix->d_smax, pool,
+                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace);
+}
+void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
+                               float* d_scores, hipStream_t st) {
+    const rr_x3_scratch s = rr_x3_scratch_of(ix);
+    hipLaunchKernelGGL(rr_select_rescored, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, s.mtiles, s.count, s.tau,
+                       s.sc, pool, ix->row_offset, d_rows, d_scores, s.fb, ix->d_sel_trace);
+}
+
 // ------------------------------------------------------------------ l2 normalize
 // l2_normalize (utils.py:40-44): x / max(||x||, eps), one 64-lane wave per row.
 // (numpy's norm is sqrt of a pairwise float32 sum of squares; this sum order differs
@@ -761,7 +917,7 @@ static int rr_ensure_scratch(rr_index* ix, int nq) {
     ix->scratch_q = 0;
     const size_t groups_cap = (size_t)RR_MAX_SCAN_WAVES;   // one group maximum per scan wave
     RR_HIP_TRY(hipMalloc(&ix->d_sims, sizeof(float) * (size_t)nq * n_tiles * 64));
-    RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * (size_t)nq * n_tiles));
+    RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * (size_t)nq * n_tiles * 4));   // x4: per-M-tile maxima of the split-operand scan
     RR_HIP_TRY(hipMalloc(&ix->d_smax, sizeof(uint32_t) * (size_t)nq * groups_cap));
     ix->scratch_q = nq;
     return RR_OK;
@@ -805,9 +961,9 @@ void rr_scan_events_end(rr_index* ix, int slot, hipStream_t st) {
     if (ix->ring_head - ix->ring_tail > rr_index::kRing) ix->ring_tail = ix->ring_head - rr_index::kRing;
 }
 void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
-                      float* d_scores, hipStream_t st) {
+                      float* d_scores, hipStream_t st, const int32_t* only_if) {
     hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
-                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace);
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, only_if);
 }
 int rr_resident_waves(const void* kernel, int threads, int device) {
     int per_cu = 0, cus = 0;
@@ -862,7 +1018,7 @@ static int rr_dense_chunk(rr_index* ix, const float* d_q, int nq, int pool, int6
         ix->timing_valid = true;
     }
     hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
-                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace);
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
@@ -893,7 +1049,7 @@ static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool,
     ix->ring_head++;
     if (ix->ring_head - ix->ring_tail > rr_index::kRing) ix->ring_tail = ix->ring_head - rr_index::kRing;
     hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
-                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace);
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
@@ -1014,6 +1170,13 @@ extern "C" int rr_index_last_scan_ms(rr_index* ix, float* out_ms) {
     RR_HIP_TRY(hipSetDevice(ix->device));
     RR_HIP_TRY(hipEventSynchronize(ix->ev1));
     RR_HIP_TRY(hipEventElapsedTime(out_ms, ix->ev0, ix->ev1));
+    return RR_OK;
+}
+
+extern "C" int rr_index_set_scan_mode(rr_index* ix, int32_t mode) {
+    RR_REQUIRE(ix != nullptr, "null index");
+    RR_REQUIRE(mode == RR_SCAN_MODE_DEFAULT || mode == RR_SCAN_MODE_STORED, "unknown scan mode %d", mode);
+    ix->scan_mode = mode;
     return RR_OK;
 }
 

@@ -59,11 +59,86 @@ __device__ __forceinline__ unsigned int rr_pack_hi(float lo_elem, float hi_elem)
     return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
 }
 
-template <int NQT, bool A_BF16>
+// The arithmetic of one K-block (32 dims) of one 16-row M-tile x 16-query tile.  The scan kernel and
+// the rescoring kernel both go through these two functions, in the same K-block order, so a score
+// recomputed by rr_rescore_x3 equals the scan's bit for bit.
+struct rr_x3_afrag { bf16x8 a1, a2, a3; };
+
+template <bool A_BF16>
+__device__ __forceinline__ rr_x3_afrag rr_x3_split(u32x4 lo_unit, u32x4 hi_unit) {
+    rr_x3_afrag f;
+    if (A_BF16) {
+        f.a1 = __builtin_bit_cast(bf16x8, lo_unit);        // the stored element is one exact bf16 term
+        f.a2 = f.a1;
+        f.a3 = f.a1;
+        return f;
+    }
+    const f32x4 lo = __builtin_bit_cast(f32x4, lo_unit);
+    const f32x4 hi = __builtin_bit_cast(f32x4, hi_unit);
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    float h1[8], h2[8], h3[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h1[e] = __uint_as_float(__float_as_uint(x[e]) & 0xFFFF0000u);
+        const float r1 = x[e] - h1[e];
+        h2[e] = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+        h3[e] = r1 - h2[e];
+    }
+    u32x4 p1, p2, p3;
+    p1.x = rr_pack_hi(h1[0], h1[1]); p1.y = rr_pack_hi(h1[2], h1[3]);
+    p1.z = rr_pack_hi(h1[4], h1[5]); p1.w = rr_pack_hi(h1[6], h1[7]);
+    p2.x = rr_pack_hi(h2[0], h2[1]); p2.y = rr_pack_hi(h2[2], h2[3]);
+    p2.z = rr_pack_hi(h2[4], h2[5]); p2.w = rr_pack_hi(h2[6], h2[7]);
+    p3.x = rr_pack_hi(h3[0], h3[1]); p3.y = rr_pack_hi(h3[2], h3[3]);
+    p3.z = rr_pack_hi(h3[4], h3[5]); p3.w = rr_pack_hi(h3[6], h3[7]);
+    f.a1 = __builtin_bit_cast(bf16x8, p1);
+    f.a2 = __builtin_bit_cast(bf16x8, p2);
+    f.a3 = __builtin_bit_cast(bf16x8, p3);
+    return f;
+}
+
+template <bool A_BF16>
+__device__ __forceinline__ void rr_x3_mma(const rr_x3_afrag& f, bf16x8 q1, bf16x8 q2, bf16x8 q3, f32x4& acc) {
+    if (A_BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, q3, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, q2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, q1, acc, 0, 0, 0);
+    } else {                                                 // smallest terms first
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a3, q1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, q3, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a2, q2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a2, q1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, q2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, q1, acc, 0, 0, 0);
+    }
+}
+
+// NaN scores and pad rows rank last (rows row0 .. row0+3 of one query)
+__device__ __forceinline__ f32x4 rr_x3_canon(f32x4 v, int64_t row0, int64_t n_rows) {
+    v.x = (row0 + 0 < n_rows && v.x == v.x) ? v.x : -INFINITY;
+    v.y = (row0 + 1 < n_rows && v.y == v.y) ? v.y : -INFINITY;
+    v.z = (row0 + 2 < n_rows && v.z == v.z) ? v.z : -INFINITY;
+    v.w = (row0 + 3 < n_rows && v.w == v.w) ? v.w : -INFINITY;
+    return v;
+}
+
+// STORE = true writes every score (M-tile-major) as well as the tile / group maxima: the fallback
+// for batches whose candidate lists overflow the rescoring path, launched with `fallback` flags and
+// returning at once when no query of the batch raised its flag.  STORE = false (the normal scan)
+// writes only the maxima: the score stores cost more than a third of the scan time
+// (tools/x3 ablation: 3.35 -> 2.52 ms at 64 queries, 2.78 -> 2.43 ms at 16), the candidate tiles are
+// rescored afterwards by rr_rescore_x3 instead (~1 % of the matrix per 64 queries).
+template <int NQT, bool A_BF16, bool STORE>
 __global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_x3(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ planes,  // [3][16*NQT][48] units
-    float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax) {
+    float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax,
+    const int32_t* __restrict__ fallback, int n_flags) {
     constexpr int THREADS = NQT == 4 ? 512 : 256;
+    if (STORE && fallback) {
+        int any = 0;
+        for (int i = 0; i < n_flags; ++i) any |= fallback[i];
+        if (!any) return;                                  // wave-uniform: nobody needs the stored scores
+    }
     constexpr int QN = 16 * NQT;
     constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
     constexpr int RING = A_BF16 ? 12 : 24;            // units a lane holds per M-tile
@@ -126,6 +201,7 @@ __global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_x3(
 #pragma unroll 1
     for (int64_t mt = m0; mt < m1; ++mt) {
         const u32x4* pn = row_ptr(mt + 1);
+        const bool maxima_pending = (mt & 3) == 0 && mt > m0;
         f32x4 acc[NQT];
 #pragma unroll
         for (int t = 0; t < NQT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -142,43 +218,23 @@ __global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_x3(
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
                     qf[t][pl] = __builtin_bit_cast(bf16x8, qs[(pl * QN + 16 * t + r) * RR_X3_UNITS + (u ^ r)]);
-            bf16x8 a1, a2, a3;
             if (b % 6 == 0) {
                 // The ring is refilled in two bursts per M-tile (units of K-blocks 0-5 after block 5,
                 // of K-blocks 6-11 after block 11): a burst asks for 6 adjacent 128-B lines of each
                 // of the 16 rows at once, which keeps the DRAM pages open, where one line per row
                 // every K-block does not.  Younger operations than the burst this half needs: the
-                // other half's burst + the score stores in between.
+                // other half's burst, and the NQT stores of the previous M-tile's epilogue (score
+                // stores when STORE -- its maxima only make the wait conservative --, else the
+                // M-tile maxima written after every fourth M-tile).
                 constexpr int H = RING / 2;
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(H + NQT) : "memory");
+                if (STORE || maxima_pending) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(H + NQT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(H) : "memory");
 #pragma unroll
                 for (int j = 0; j < H; ++j) asm volatile("" : "+v"(a[(b / 6) * H + j]));   // uses stay below the wait
             }
-            if (A_BF16) {
-                a1 = __builtin_bit_cast(bf16x8, to_mfma_lanes(a[b]));
-            } else {
-                const f32x4 lo = __builtin_bit_cast(f32x4, to_mfma_lanes(a[2 * b]));
-                const f32x4 hi = __builtin_bit_cast(f32x4, to_mfma_lanes(a[2 * b + 1]));
-                float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                float h1[8], h2[8], h3[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    h1[e] = __uint_as_float(__float_as_uint(x[e]) & 0xFFFF0000u);
-                    const float r1 = x[e] - h1[e];
-                    h2[e] = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
-                    h3[e] = r1 - h2[e];
-                }
-                u32x4 p1, p2, p3;
-                p1.x = rr_pack_hi(h1[0], h1[1]); p1.y = rr_pack_hi(h1[2], h1[3]);
-                p1.z = rr_pack_hi(h1[4], h1[5]); p1.w = rr_pack_hi(h1[6], h1[7]);
-                p2.x = rr_pack_hi(h2[0], h2[1]); p2.y = rr_pack_hi(h2[2], h2[3]);
-                p2.z = rr_pack_hi(h2[4], h2[5]); p2.w = rr_pack_hi(h2[6], h2[7]);
-                p3.x = rr_pack_hi(h3[0], h3[1]); p3.y = rr_pack_hi(h3[2], h3[3]);
-                p3.z = rr_pack_hi(h3[4], h3[5]); p3.w = rr_pack_hi(h3[6], h3[7]);
-                a1 = __builtin_bit_cast(bf16x8, p1);
-                a2 = __builtin_bit_cast(bf16x8, p2);
-                a3 = __builtin_bit_cast(bf16x8, p3);
-            }
+            const rr_x3_afrag af = A_BF16 ? rr_x3_split<true>(to_mfma_lanes(a[b]), u32x4{})
+                                          : rr_x3_split<false>(to_mfma_lanes(a[A_BF16 ? b : 2 * b]),
+                                                               to_mfma_lanes(a[A_BF16 ? b : 2 * b + 1]));
 #pragma unroll
             for (int t = 0; t < NQT; ++t) {
                 if (t % TB == 0 && t + TB < NQT) {            // prefetch the next group of query tiles
@@ -188,18 +244,7 @@ __global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_x3(
                         for (int pl = 0; pl < 3; ++pl)
                             qf[t2][pl] = __builtin_bit_cast(bf16x8, qs[(pl * QN + 16 * t2 + r) * RR_X3_UNITS + (u ^ r)]);
                 }
-                if (A_BF16) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][0], acc[t], 0, 0, 0);
-                } else {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, qf[t][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, qf[t][1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, qf[t][0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][0], acc[t], 0, 0, 0);
-                }
+                rr_x3_mma<A_BF16>(af, qf[t][0], qf[t][1], qf[t][2], acc[t]);
             }
             if (b % 6 == 5) {
                 // this half's units of the next M-tile, as one burst, into the registers just consumed
@@ -217,20 +262,23 @@ __global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_x3(
         const bool tile_end = (mt & 3) == 3;
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
-            f32x4 v = acc[t];
-            v.x = (row0 + 0 < G.n_rows && v.x == v.x) ? v.x : -INFINITY;   // NaN scores and pad rows rank last
-            v.y = (row0 + 1 < G.n_rows && v.y == v.y) ? v.y : -INFINITY;
-            v.z = (row0 + 2 < G.n_rows && v.z == v.z) ? v.z : -INFINITY;
-            v.w = (row0 + 3 < G.n_rows && v.w == v.w) ? v.w : -INFINITY;
-            *reinterpret_cast<f32x4*>(sims + ((mt * QN + 16 * t + r) * 16 + 4 * kg)) = v;
+            const f32x4 v = rr_x3_canon(acc[t], row0, G.n_rows);
+            if (STORE) *reinterpret_cast<f32x4*>(sims + ((mt * QN + 16 * t + r) * 16 + 4 * kg)) = v;
             float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
             m4 = fmaxf(m4, __shfl_xor(m4, 16, 64));
-            m4 = fmaxf(m4, __shfl_xor(m4, 32, 64));
-            tile_max[t] = fmaxf(tile_max[t], m4);
-            if (tile_end) {
-                if (kg == 0) gmax[(mt >> 2) * QN + 16 * t + r] = tile_max[t];
-                gm[t] = fmaxf(gm[t], tile_max[t]);
-                tile_max[t] = -INFINITY;
+            m4 = fmaxf(m4, __shfl_xor(m4, 32, 64));      // maximum of the M-tile for query 16*t + r, in all four kg lanes
+            if (STORE) {
+                tile_max[t] = fmaxf(tile_max[t], m4);
+                if (tile_end) {
+                    if (kg == 0) gmax[(mt >> 2) * QN + 16 * t + r] = tile_max[t];
+                    gm[t] = fmaxf(gm[t], tile_max[t]);
+                    tile_max[t] = -INFINITY;
+                }
+            } else {
+                // lane (r, kg) keeps the maximum of M-tile kg of the 64-row tile: [tile][query][4]
+                gm[t] = fmaxf(gm[t], m4);
+                if ((int)(mt & 3) == kg) tile_max[t] = m4;
+                if (tile_end) gmax[(((mt >> 2) * QN + 16 * t + r) << 2) + kg] = tile_max[t];
             }
         }
     }
@@ -241,25 +289,105 @@ __global__ __launch_bounds__((NQT == 4 ? 512 : 256), 2) void rr_scan_mfma_x3(
     }
 }
 
+// Recomputes the 16 scores of every M-tile rr_select_mtiles listed, one wave per (query, M-tile):
+// same load mapping, lane permutation, operand split, MFMA order and K-block order as the scan,
+// with the query's planes in every B column (an output element depends only on its own row of A
+// and column of B), so each score is the scan's bit for bit.  Output: sc[query][slot][16].
+template <bool A_BF16>
+__global__ __launch_bounds__(256) void rr_rescore_x3(
+    const u32x4* __restrict__ mat, int64_t n_rows, const u32x4* __restrict__ planes, int QN,
+    const uint32_t* __restrict__ mtiles, const int32_t* __restrict__ count, const int32_t* __restrict__ fb,
+    float* __restrict__ sc) {
+    constexpr int ROWU = A_BF16 ? 48 : 96;
+    constexpr int RING = A_BF16 ? 12 : 24;
+    const int q = blockIdx.y;
+    if (fb[q]) return;
+    const int n = count[q];
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, kg = lane >> 4;
+    const int lrow = lane >> 2, lkg = lane & 3;
+    const int bperm_src = 4 * (4 * r + kg);
+    auto to_mfma_lanes = [&](u32x4 v) {
+        u32x4 o;
+        o.x = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_src, (int)v.x);
+        o.y = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_src, (int)v.y);
+        o.z = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_src, (int)v.z);
+        o.w = (unsigned)__builtin_amdgcn_ds_bpermute(bperm_src, (int)v.w);
+        return o;
+    };
+    for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n; slot += gridDim.x * 4) {
+        const int64_t mt = mtiles[(int64_t)q * RR_X3_MCAP + slot];
+        int64_t row = mt * 16 + lrow;
+        row = row < n_rows ? row : n_rows - 1;
+        const u32x4* p = mat + row * ROWU + lkg;
+        u32x4 a[RING];
+#pragma unroll
+        for (int j = 0; j < RING; ++j) a[j] = p[RR_X3_OFF(j) / 16];
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 12; ++b) {
+            const int u = 4 * b + kg;
+            const bf16x8 q1 = __builtin_bit_cast(bf16x8, planes[(0 * QN + q) * RR_X3_UNITS + u]);
+            const bf16x8 q2 = __builtin_bit_cast(bf16x8, planes[(1 * QN + q) * RR_X3_UNITS + u]);
+            const bf16x8 q3 = __builtin_bit_cast(bf16x8, planes[(2 * QN + q) * RR_X3_UNITS + u]);
+            const rr_x3_afrag af = A_BF16 ? rr_x3_split<true>(to_mfma_lanes(a[b]), u32x4{})
+                                          : rr_x3_split<false>(to_mfma_lanes(a[A_BF16 ? b : 2 * b]),
+                                                               to_mfma_lanes(a[A_BF16 ? b : 2 * b + 1]));
+            rr_x3_mma<A_BF16>(af, q1, q2, q3, acc);
+        }
+        const f32x4 v = rr_x3_canon(acc, mt * 16 + 4 * kg, n_rows);
+        if (r == 0) *reinterpret_cast<f32x4*>(sc + ((int64_t)q * RR_X3_MCAP + slot) * 16 + 4 * kg) = v;
+    }
+}
+
+static bool rr_x3_stored_path(const rr_index* ix) {
+    if (ix->scan_mode == RR_SCAN_MODE_STORED) return true;
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("RR_X3_STORED");       // diagnostic: single-pass scan that stores every score
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 template <int NQT, bool A_BF16>
 static int rr_dense_chunk_x3_t(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st) {
     constexpr int THREADS = NQT == 4 ? 512 : 256;
     constexpr int QN = 16 * NQT;
     static int waves = 0;
-    if (!waves) waves = rr_resident_waves((const void*)rr_scan_mfma_x3<NQT, A_BF16>, THREADS, ix->device);
+    if (!waves) waves = rr_resident_waves((const void*)rr_scan_mfma_x3<NQT, A_BF16, false>, THREADS, ix->device);
     rr_scan_geom G = rr_make_geom(ix, waves / 4);
     G.qs = QN;
     // the split query planes live behind the staged queries in the index's query buffer
     unsigned short* planes = reinterpret_cast<unsigned short*>(ix->d_qplanes);
+    const u32x4* mat = reinterpret_cast<const u32x4*>(ix->d_matrix);
+    const u32x4* pl4 = reinterpret_cast<const u32x4*>(planes);
+    const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
+    const rr_x3_scratch X = rr_x3_scratch_of(ix);
     hipLaunchKernelGGL(rr_split_queries, dim3((QN * 384 + 255) / 256), dim3(256), 0, st, d_q, planes, QN,
                        A_BF16 ? 0 : 1);
+    if (rr_x3_stored_path(ix)) {
+        const int slot = rr_scan_events_begin(ix, st);
+        hipLaunchKernelGGL((rr_scan_mfma_x3<NQT, A_BF16, true>), grid, block, 0, st, mat, G, pl4, ix->d_sims,
+                           ix->d_gmax, ix->d_smax, (const int32_t*)nullptr, 0);
+        rr_scan_events_end(ix, slot, st);
+        rr_launch_select(ix, G, nq, pool, d_rows, d_scores, st);
+        RR_HIP_TRY(hipGetLastError());
+        return RR_OK;
+    }
     const int slot = rr_scan_events_begin(ix, st);
-    hipLaunchKernelGGL((rr_scan_mfma_x3<NQT, A_BF16>), dim3((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)),
-                       dim3(THREADS), 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
-                       reinterpret_cast<const u32x4*>(planes), ix->d_sims, ix->d_gmax, ix->d_smax);
+    hipLaunchKernelGGL((rr_scan_mfma_x3<NQT, A_BF16, false>), grid, block, 0, st, mat, G, pl4, ix->d_sims,
+                       ix->d_gmax, ix->d_smax, (const int32_t*)nullptr, 0);
     rr_scan_events_end(ix, slot, st);
-    rr_launch_select(ix, G, nq, pool, d_rows, d_scores, st);
+    rr_launch_select_mtiles(ix, G, nq, pool, st);
+    hipLaunchKernelGGL((rr_rescore_x3<A_BF16>), dim3(64, nq), dim3(256), 0, st, mat, G.n_rows, pl4, QN,
+                       X.mtiles, X.count, X.fb, X.sc);
+    rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st);
+    // Fallback for the queries that raised their flag: both launches return at once otherwise.
+    hipLaunchKernelGGL((rr_scan_mfma_x3<NQT, A_BF16, true>), grid, block, 0, st, mat, G, pl4, ix->d_sims,
+                       ix->d_gmax, ix->d_smax, (const int32_t*)X.fb, nq);
+    rr_launch_select(ix, G, nq, pool, d_rows, d_scores, st, X.fb);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
@@ -276,3 +404,4 @@ int rr_dense_chunk_x3(rr_index* ix, const float* d_q, int nq, int pool, int64_t*
     return b ? rr_dense_chunk_x3_t<4, true>(ix, d_q, nq, pool, d_rows, d_scores, st)
              : rr_dense_chunk_x3_t<4, false>(ix, d_q, nq, pool, d_rows, d_scores, st);
 }
+

@@ -130,6 +130,11 @@ class ProductIndex:
         _lib.check(_lib.load().rr_index_select_trace(self._h, out), "rr_index_select_trace")
         return tuple(out)
 
+    def set_scan_mode(self, stored: bool) -> None:
+        """Diagnostic: True forces the batched scan's single pass that stores every score
+        (RR_SCAN_MODE_STORED); False restores the two-pass default."""
+        _lib.check(_lib.load().rr_index_set_scan_mode(self._h, 1 if stored else 0), "rr_index_set_scan_mode")
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             _lib.load().rr_index_destroy(self._h)

@@ -105,6 +105,47 @@ def test_matrix_core_scan_ragged_tail_and_ties():
         check_against_oracle(V, Q, min(150, n))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("batch", [9, 16, 17, 40, 64])
+def test_two_pass_batched_scan_equals_the_stored_score_pass(batch, dtype):
+    # default: the scan keeps only M-tile maxima and the candidate M-tiles are rescored
+    # (trace[0] == 2); diagnostic mode: the single pass that stores every score.  Bit-equal.
+    V = synth.unit_rows(300_000, 384, 77)
+    V[1000:1040] = V[11]                         # ties across M-tiles
+    Q = synth.unit_rows(batch, 384, 78)
+    Q[3] = V[11]
+    ix = ProductIndex(V) if dtype == "f32" else ProductIndex.from_rows(V, dtype="bf16")
+    rows2, sc2 = ix.dense_topk(Q, 150)
+    assert ix.select_trace()[0] == 2, "the two-pass path must be the one that ran"
+    ix.set_scan_mode(stored=True)
+    rows1, sc1 = ix.dense_topk(Q, 150)
+    assert ix.select_trace()[0] == 1
+    ix.set_scan_mode(stored=False)
+    assert np.array_equal(rows1, rows2) and np.array_equal(sc1.view(np.uint32), sc2.view(np.uint32))
+    if dtype == "f32":
+        check_against_oracle(V, Q[:6], 150, index=ix)     # (VALU path for <= 4; 6 -> matrix cores)
+    ix.close()
+
+
+def test_two_pass_falls_back_per_query_on_massive_ties():
+    # query 0 ties on > 2048 M-tiles (its candidate list overflows -> flagged, stored-score fallback);
+    # the other queries of the batch stay on the two-pass path.  Both kinds must be exact.
+    V = synth.unit_rows(200_000, 384, 91)
+    V[::50] = V[3]                               # 4000 copies of row 3, spread over 4000 M-tiles
+    Q = synth.unit_rows(20, 384, 92)
+    Q[0] = V[3]
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(Q, 150)
+    assert rows[0].tolist() == sorted({3} | set(range(0, 50 * 150, 50)))[:150]   # equal scores -> ascending row
+    assert np.all(scores[0] == scores[0][0])
+    ix.set_scan_mode(stored=True)
+    rows1, sc1 = ix.dense_topk(Q, 150)
+    ix.set_scan_mode(stored=False)
+    assert np.array_equal(rows1, rows) and np.array_equal(sc1.view(np.uint32), scores.view(np.uint32))
+    check_against_oracle(V, Q[:8], 150, index=ix)
+    ix.close()
+
+
 @pytest.mark.parametrize("pool", [255, 256, 257, 1000, 2048])
 def test_large_pools_cross_the_fast_path_limits(pool):
     # the 3-level selection opens at most 256 groups per level in LDS; larger pools fall back
