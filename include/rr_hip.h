@@ -216,6 +216,11 @@ int rr_reviews_best_dev(rr_reviews* rv, const float* d_queries, int32_t n_querie
                         const int64_t* d_rows, int32_t pool, int64_t row_offset, int32_t max_review_id,
                         float* d_best_score, int32_t* d_best_id, void* stream);
 
+/* Development aid (tools/x3w_ablate.py): times ablated variants of the 64-query fp32 batched scan
+ * (bit 0: no operand split, bit 1: no B-fragment reads, bit 2: no MFMA, bit 3: no lane swap).
+ * Leaves garbage in the scan scratch; never part of a search. */
+int rr_debug_scan_x3w(rr_index* ix, int32_t variant, int32_t reps, float* out_ms);
+
 /* Stream helpers for callers that chain *_dev calls. */
 int rr_index_stream(rr_index* ix, void** out_stream);
 int rr_index_synchronize(rr_index* ix);

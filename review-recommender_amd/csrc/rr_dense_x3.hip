@@ -23,26 +23,21 @@
 // to LDS, XOR-swizzled in 16-B units (unit u of query q sits at u ^ (q & 15)) so the B-fragment
 // ds_read_b128 is conflict-free.  64 queries x 3 planes = 144 KB: one 512-thread workgroup per
 // CU, 8 waves x 24 KB in flight.
-#include "rr_common.h"
-#include "rr_dense.h"
+#include "rr_x3.h"
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-#define RR_X3_UNITS 48   // 16-byte units (8 bf16) per 384-d query / bf16 row
-
-// queries (slots x 384 fp32) -> planes[3][slots][384] bf16 (truncating split, exact sum).
-// `interleave`: inside every 32-dim K-block, MFMA k-slot (kg, j) stands for dim 4*kg + j (j < 4) or
-// 16 + 4*kg + (j - 4): the order in which an fp32-matrix lane holds its two 16-byte loads when the
-// four lanes of a row read 64 contiguous bytes per instruction (see RR_X3_OFF).
+// queries (slots x 384 fp32) -> planes[3][slots][384] bf16 (truncating split, exact sum), in the k
+// order `order` (rr_x3.h) inside every 32-dim group.
 __global__ void rr_split_queries(const float* __restrict__ q, unsigned short* __restrict__ planes, int slots,
-                                 int interleave) {
+                                 int order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= slots * 384) return;
     int src = i;
-    if (interleave) {
+    if (order == RR_X3_ORDER_PAIR64) {
         const int e = i & 31, kg = e >> 3, j = e & 7;
         src = (i & ~31) + (j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4));
+    } else if (order == RR_X3_ORDER_WIDE_BF16) {
+        const int e = i & 31, v = e >> 4, h = (e >> 3) & 1, j = e & 7;
+        src = (i & ~31) + 16 * h + 8 * v + j;
     }
     const float x = q[src];
     const float x1 = __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
@@ -53,48 +48,8 @@ __global__ void rr_split_queries(const float* __restrict__ q, unsigned short* __
     planes[slots * 384 + i] = (unsigned short)(__float_as_uint(x2) >> 16);
     planes[2 * slots * 384 + i] = (unsigned short)(__float_as_uint(x3) >> 16);
 }
-
-__device__ __forceinline__ unsigned int rr_pack_hi(float lo_elem, float hi_elem) {
-    // {hi16(hi_elem), hi16(lo_elem)}: element order inside a bf16 pair is low half first
-    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
-}
-
-// The arithmetic of one K-block (32 dims) of one 16-row M-tile x 16-query tile.  The scan kernel and
-// the rescoring kernel both go through these two functions, in the same K-block order, so a score
-// recomputed by rr_rescore_x3 equals the scan's bit for bit.
-struct rr_x3_afrag { bf16x8 a1, a2, a3; };
-
-template <bool A_BF16>
-__device__ __forceinline__ rr_x3_afrag rr_x3_split(u32x4 lo_unit, u32x4 hi_unit) {
-    rr_x3_afrag f;
-    if (A_BF16) {
-        f.a1 = __builtin_bit_cast(bf16x8, lo_unit);        // the stored element is one exact bf16 term
-        f.a2 = f.a1;
-        f.a3 = f.a1;
-        return f;
-    }
-    const f32x4 lo = __builtin_bit_cast(f32x4, lo_unit);
-    const f32x4 hi = __builtin_bit_cast(f32x4, hi_unit);
-    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    float h1[8], h2[8], h3[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        h1[e] = __uint_as_float(__float_as_uint(x[e]) & 0xFFFF0000u);
-        const float r1 = x[e] - h1[e];
-        h2[e] = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
-        h3[e] = r1 - h2[e];
-    }
-    u32x4 p1, p2, p3;
-    p1.x = rr_pack_hi(h1[0], h1[1]); p1.y = rr_pack_hi(h1[2], h1[3]);
-    p1.z = rr_pack_hi(h1[4], h1[5]); p1.w = rr_pack_hi(h1[6], h1[7]);
-    p2.x = rr_pack_hi(h2[0], h2[1]); p2.y = rr_pack_hi(h2[2], h2[3]);
-    p2.z = rr_pack_hi(h2[4], h2[5]); p2.w = rr_pack_hi(h2[6], h2[7]);
-    p3.x = rr_pack_hi(h3[0], h3[1]); p3.y = rr_pack_hi(h3[2], h3[3]);
-    p3.z = rr_pack_hi(h3[4], h3[5]); p3.w = rr_pack_hi(h3[6], h3[7]);
-    f.a1 = __builtin_bit_cast(bf16x8, p1);
-    f.a2 = __builtin_bit_cast(bf16x8, p2);
-    f.a3 = __builtin_bit_cast(bf16x8, p3);
-    return f;
+void rr_launch_split_queries(const float* d_q, unsigned short* planes, int slots, int order, hipStream_t st) {
+    hipLaunchKernelGGL(rr_split_queries, dim3((slots * 384 + 255) / 256), dim3(256), 0, st, d_q, planes, slots, order);
 }
 
 template <bool A_BF16>
@@ -111,15 +66,6 @@ __device__ __forceinline__ void rr_x3_mma(const rr_x3_afrag& f, bf16x8 q1, bf16x
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, q2, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, q1, acc, 0, 0, 0);
     }
-}
-
-// NaN scores and pad rows rank last (rows row0 .. row0+3 of one query)
-__device__ __forceinline__ f32x4 rr_x3_canon(f32x4 v, int64_t row0, int64_t n_rows) {
-    v.x = (row0 + 0 < n_rows && v.x == v.x) ? v.x : -INFINITY;
-    v.y = (row0 + 1 < n_rows && v.y == v.y) ? v.y : -INFINITY;
-    v.z = (row0 + 2 < n_rows && v.z == v.z) ? v.z : -INFINITY;
-    v.w = (row0 + 3 < n_rows && v.w == v.w) ? v.w : -INFINITY;
-    return v;
 }
 
 // STORE = true writes every score (M-tile-major) as well as the tile / group maxima: the fallback
@@ -340,7 +286,7 @@ __global__ __launch_bounds__(256) void rr_rescore_x3(
     }
 }
 
-static bool rr_x3_stored_path(const rr_index* ix) {
+bool rr_x3_stored_path(const rr_index* ix) {
     if (ix->scan_mode == RR_SCAN_MODE_STORED) return true;
     static int v = -1;
     if (v < 0) {
@@ -365,8 +311,7 @@ static int rr_dense_chunk_x3_t(rr_index* ix, const float* d_q, int nq, int pool,
     const u32x4* pl4 = reinterpret_cast<const u32x4*>(planes);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     const rr_x3_scratch X = rr_x3_scratch_of(ix);
-    hipLaunchKernelGGL(rr_split_queries, dim3((QN * 384 + 255) / 256), dim3(256), 0, st, d_q, planes, QN,
-                       A_BF16 ? 0 : 1);
+    rr_launch_split_queries(d_q, planes, QN, A_BF16 ? RR_X3_ORDER_NATURAL : RR_X3_ORDER_PAIR64, st);
     if (rr_x3_stored_path(ix)) {
         const int slot = rr_scan_events_begin(ix, st);
         hipLaunchKernelGGL((rr_scan_mfma_x3<NQT, A_BF16, true>), grid, block, 0, st, mat, G, pl4, ix->d_sims,
@@ -395,6 +340,12 @@ static int rr_dense_chunk_x3_t(rr_index* ix, const float* d_q, int nq, int pool,
 int rr_dense_chunk_x3(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                       float* d_scores, hipStream_t st) {
     const bool b = ix->dtype == RR_DTYPE_BF16;
+    static int narrow = -1;
+    if (narrow < 0) {
+        const char* e = getenv("RR_X3_NARROW");       // diagnostic: 16x16x32 tiles for every batch size
+        narrow = (e && e[0] == '1') ? 1 : 0;
+    }
+    if (nq > 16 && !narrow) return rr_dense_chunk_x3w(ix, d_q, nq, pool, d_rows, d_scores, st);
     if (nq <= 16)
         return b ? rr_dense_chunk_x3_t<1, true>(ix, d_q, nq, pool, d_rows, d_scores, st)
                  : rr_dense_chunk_x3_t<1, false>(ix, d_q, nq, pool, d_rows, d_scores, st);

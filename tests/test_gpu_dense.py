@@ -79,16 +79,18 @@ def test_batches_and_batch_invariance(batch):
     ix = ProductIndex(V)
     rows, scores = check_against_oracle(V, Q, 150, ix)
     # Batches of <= 4 run the per-row-chain kernel: a query's answer is bitwise the same in any
-    # such batch.  Larger batches run the matrix-core kernel, whose (equally fixed) summation
-    # order differs: there the two agree to f32 rounding and each is checked against the oracle.
+    # such batch.  Larger batches run a matrix-core kernel (16x16x32 tiles for 5..16 queries,
+    # 32x32x16 tiles for 17..64), whose (equally fixed) summation orders differ: across kernels the
+    # answers agree to f32 rounding, and each is checked against the oracle.
     r1, s1 = ix.dense_topk(Q[-1:], 150)
-    tail = batch % 64                      # queries are taken 64 at a time; a tail of <= 4 runs per-row chains
-    if tail != 0 and tail <= 4:
+    tail = batch % 64 or 64                # queries are taken 64 at a time; the last query sits in the tail chunk
+    if tail <= 4:
         assert np.array_equal(r1[0], rows[-1]) and np.array_equal(s1[0], scores[-1])
     else:
         np.testing.assert_allclose(s1[0], scores[-1], atol=2e-7, rtol=0)
-        # the matrix-core kernel is itself batch-invariant: same query in another big batch
-        Q2 = np.concatenate([synth.unit_rows(4 + (batch % 7), 384, 13), Q[-1:]])
+        # each matrix-core kernel is itself batch-invariant: same query in another batch of its class
+        extra = 4 + (batch % 7) if tail <= 16 else 20 + (batch % 7)
+        Q2 = np.concatenate([synth.unit_rows(extra, 384, 13), Q[-1:]])
         r2, s2 = ix.dense_topk(Q2, 150)
         assert np.array_equal(r2[-1], rows[-1]) and np.array_equal(s2[-1], scores[-1])
     ix.close()

@@ -9,6 +9,8 @@ from review_recommender_amd.index import ProductIndex
 n = int(sys.argv[1]); dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
 lib = _lib.load()
 mat = torch.randn((n, 384), device="cuda"); mat /= mat.norm(dim=1, keepdim=True)
+if len(sys.argv) > 3 and sys.argv[3] == "zeros":     # power experiment: same instruction stream, no bit toggling
+    mat.zero_()
 if dtype == "bf16":
     mat = mat.to(torch.bfloat16)
 ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=mat.data_ptr(), keepalive=mat, dtype=dtype)
