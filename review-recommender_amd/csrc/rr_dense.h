@@ -16,6 +16,9 @@ struct rr_scan_geom {
                               //    (rr_scan_mfma_f32 with Q = 16 * NQT query slots: every store of a wave is
                               //    one contiguous block of whole 128-B lines)
     int64_t n_pad;            // 64 * n_tiles
+    int32_t mm_pairs;         // M-tile maxima of the two-pass path: 0 = [tile][Q][4] (rr_scan_mfma_x3),
+                              // 1 = [32-row tile][Q][2] (rr_scan_x3w: whole lines per store)
+    int32_t _pad;
 };
 
 

@@ -782,8 +782,15 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
         for (int64_t i = tid; i < n2; i += RR_SEL_THREADS) {
             const int64_t t = (int64_t)list2[i / C] * C + (i % C);
             if (t >= G.n_tiles) continue;
-            const f32x4 m = mm4[t * QS + q];
-            const float v[4] = {m.x, m.y, m.z, m.w};
+            float v[4];
+            if (G.mm_pairs) {
+                const float2 m0 = reinterpret_cast<const float2*>(mmax)[(2 * t) * QS + q];
+                const float2 m1 = reinterpret_cast<const float2*>(mmax)[(2 * t + 1) * QS + q];
+                v[0] = m0.x, v[1] = m0.y, v[2] = m1.x, v[3] = m1.y;
+            } else {
+                const f32x4 m = mm4[t * QS + q];
+                v[0] = m.x, v[1] = m.y, v[2] = m.z, v[3] = m.w;
+            }
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
                 if (rr_f2key(v[sub]) >= tau) {
@@ -947,6 +954,8 @@ rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks) {
     G.tiles_per_wave = (G.n_tiles + max_waves - 1) / max_waves;
     G.n_waves = (int32_t)((G.n_tiles + G.tiles_per_wave - 1) / G.tiles_per_wave);
     G.qs = 0;
+    G.mm_pairs = 0;
+    G._pad = 0;
     return G;
 }
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ void rr_x3w_to_mfma_lanes(u32x4 x, u32x4 y, u32x4& lo
 }
 
 // DBG != 0: timing-only ablations for tools/x3w_ablate.py (wrong results): bit 0 drops the operand
-// split, bit 1 the B-fragment LDS reads, bit 2 the MFMAs, bit 3 the lane swaps; bit 4 stamps the shader clock around
+// split, bit 1 the B-fragment LDS reads, bit 2 the MFMAs, bit 3 the lane swaps; bit 6 skips the epilogue, bit 7 the LDS fill; bit 4 stamps the shader clock around
 // the ring waits and the epilogue and leaves per-wave {total, waits, epilogue} cycles in `sims`.
 template <int NQ2, bool A_BF16, bool STORE, int DBG = 0>
 __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr_scan_x3w(
@@ -71,8 +71,10 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
     constexpr int NTERM = A_BF16 ? 3 : 6;
     __shared__ u32x4 qs[3 * QN * RR_X3W_QSTRIDE];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 3 * QN * RR_X3_UNITS; i += THREADS)
-        qs[(i / RR_X3_UNITS) * RR_X3W_QSTRIDE + (i % RR_X3_UNITS)] = planes[i];
+    if (!(DBG & 128)) {
+        for (int i = tid; i < 3 * QN * RR_X3_UNITS; i += THREADS)
+            qs[(i / RR_X3_UNITS) * RR_X3W_QSTRIDE + (i % RR_X3_UNITS)] = planes[i];
+    }
     __syncthreads();
 
     const int lane = tid & 63;
@@ -108,9 +110,13 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
 
     const u32x4* qlane = qs + c * RR_X3W_QSTRIDE + h;     // + (pl * QN + 32 t) * QSTRIDE + 2 * kk
     float gm[NQ2];
+    float2 pend[NQ2];                                     // !STORE: maxima of the M-tile just finished, not yet stored
     float tmax[NQ2];                                      // STORE: running maximum of the 64-row tile
 #pragma unroll
-    for (int t = 0; t < NQ2; ++t) gm[t] = tmax[t] = -INFINITY;
+    for (int t = 0; t < NQ2; ++t) {
+        gm[t] = tmax[t] = -INFINITY;
+        pend[t] = float2{-INFINITY, -INFINITY};
+    }
     long long dbg_t0 = 0, dbg_wait = 0, dbg_epi = 0;   // (dbg_wait: unused since the ring became a steady flow)
     if (DBG & 16) dbg_t0 = clock64();
 
@@ -203,10 +209,17 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
                 // spreading a half's loads over the MFMA slots of a K-step.
                 // The wait: the half holding pair np must have landed (np = 6: second half of this
                 // segment, np = 0: first half of the next).  Younger in the queue: the other half's burst
-                // (12) and at times an epilogue's few stores -- not counted: waiting for fewer than are
-                // really younger only asks the first loads of the other burst to have landed too.
+                // (12) and, in an M-tile's first segment, the NQ2 maxima stores of the previous M-tile,
+                // which are issued right behind this segment's first burst (below) precisely so that
+                // they are YOUNGER than what either wait of the segment needs: vmcnt retires in order,
+                // a store is acknowledged microseconds after issue under this read load, and a wait
+                // that covers a fresh store stalls the wave for that long (0.34 ms of a 2.8 ms scan
+                // when the stores sat in front of the next wait).  By the next wait that does cover
+                // them they are 13+ K-steps old.  (STORE: the fallback pass stores at once and waits
+                // conservatively.)
                 if (swap && (np == 6 || np == 0)) {
-                    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    if (!STORE && p == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + NQ2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
                     for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(a[(np / 6) * 12 + j]));   // uses stay below the wait
                 }
@@ -228,6 +241,15 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
                         for (int u = 0; u < 12; u += 2) RR_X3W_LOAD(a[(np / 6) * 12 + u], (np / 6) * 12 + u);          // rows 0-15: 384 B each
 #pragma unroll
                         for (int u = 1; u < 12; u += 2) RR_X3W_LOAD(a[(np / 6) * 12 + u], (np / 6) * 12 + u);          // rows 16-31
+                        if (!STORE && p == 0 && np == 5) {
+                            // maxima of the previous M-tile ([32-row tile][query][2]: 256 contiguous bytes per
+                            // store).  First M-tile of the wave: nothing pending yet -- the same count of stores
+                            // goes to its own slot, overwritten one M-tile later by this wave.
+                            const int64_t mprev = mt > m0 ? mt - 1 : mt;
+#pragma unroll
+                            for (int t = 0; t < NQ2; ++t)
+                                if (h == 0) *reinterpret_cast<float2*>(gmax + ((mprev * QN + 32 * t + c) << 1)) = pend[t];
+                        }
                     }
                     // B fragments of the next K-step, in place, each plane right after its last term here:
                     // term index after the last use of q3 | q1 | q2
@@ -251,6 +273,7 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
                 }
             }
         }
+        if (DBG & 64) continue;                           // (ablation: no epilogue)
         // lane (c, h), register 4g + i: row 8g + 4h + i of the M-tile, query 32t + c
         long long e0 = 0;
         if (DBG & 16) e0 = clock64();
@@ -281,8 +304,8 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
                     if (h == 0) gmax[(mt >> 1) * QN + 32 * t + c] = tmax[t];
                     tmax[t] = -INFINITY;
                 }
-            } else if (h == 0) {     // rr_select_mtiles' layout: [tile][query][4 M-tiles of 16 rows]
-                *reinterpret_cast<float2*>(gmax + (((mt >> 1) * QN + 32 * t + c) << 2) + 2 * (mt & 1)) = float2{m16[0], m16[1]};
+            } else {                 // rr_select_mtiles' layout (mm_pairs); stored during the next M-tile
+                pend[t] = float2{m16[0], m16[1]};
             }
         }
         if (DBG & 16) dbg_epi += clock64() - e0;
@@ -297,7 +320,10 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
     if (h == 0) {
 #pragma unroll
-        for (int t = 0; t < NQ2; ++t) smax[wave * QN + 32 * t + c] = rr_f2key(gm[t]);
+        for (int t = 0; t < NQ2; ++t) {
+            if (!STORE) *reinterpret_cast<float2*>(gmax + (((m1 - 1) * QN + 32 * t + c) << 1)) = pend[t];
+            smax[wave * QN + 32 * t + c] = rr_f2key(gm[t]);
+        }
     }
 }
 
@@ -380,6 +406,7 @@ static int rr_dense_chunk_x3w_t(rr_index* ix, const float* d_q, int nq, int pool
     if (!waves) waves = rr_resident_waves((const void*)rr_scan_x3w<NQ2, A_BF16, false>, THREADS, ix->device);
     rr_scan_geom G = rr_make_geom(ix, waves / 4);
     G.qs = QN;
+    G.mm_pairs = 1;
     unsigned short* planes = reinterpret_cast<unsigned short*>(ix->d_qplanes);
     const u32x4* mat = reinterpret_cast<const u32x4*>(ix->d_matrix);
     const u32x4* pl4 = reinterpret_cast<const u32x4*>(planes);
@@ -429,6 +456,7 @@ static float rr_debug_time_x3w(rr_index* ix, hipStream_t st, int reps) {
     const int waves = rr_resident_waves((const void*)rr_scan_x3w<2, false, false, DBG>, THREADS, ix->device);
     rr_scan_geom G = rr_make_geom(ix, waves / 4);
     G.qs = QN;
+    G.mm_pairs = 1;
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -477,6 +505,10 @@ extern "C" int rr_debug_scan_x3w(rr_index* ix, int32_t dbg, int32_t reps, float*
         case 16: *out_ms = rr_debug_time_x3w<16>(ix, st, reps); break;
         case 15: *out_ms = rr_debug_time_x3w<15>(ix, st, reps); break;
         case 47: *out_ms = rr_debug_time_x3w<47>(ix, st, reps); break;
+        case 79: *out_ms = rr_debug_time_x3w<79>(ix, st, reps); break;
+        case 143: *out_ms = rr_debug_time_x3w<143>(ix, st, reps); break;
+        case 207: *out_ms = rr_debug_time_x3w<207>(ix, st, reps); break;
+        case 64: *out_ms = rr_debug_time_x3w<64>(ix, st, reps); break;
         case 48: *out_ms = rr_debug_time_x3w<48>(ix, st, reps); break;
         case 59: *out_ms = rr_debug_time_x3w<59>(ix, st, reps); break;
         default: RR_REQUIRE(false, "unknown ablation %d", dbg);

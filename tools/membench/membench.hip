@@ -55,6 +55,76 @@ __global__ __launch_bounds__(256) void kmf(const f32x4* __restrict__ mat, long n
     if (w[0][3] + w[1][7] == 12345.678f) out[wave] = w[0][1];
 }
 
+// The wide scan's skeleton: 32-row M-tiles, ring = 12 pairs (rows 0-15 | 16-31, 64 B each) = half of
+// the rows' 1536 B, refilled by halves in bursts of 12 with vmcnt(12).  TILED = false: row-major matrix
+// (each row is visited twice, 768 B per visit); TILED = true: every 24 KB ring segment is contiguous.
+template <bool TILED, int BURST>
+__global__ __launch_bounds__(256) void kwide(const f32x4* __restrict__ mat, long n_m32, long tiles_per_wave, float* out) {
+    extern __shared__ float pad[];
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long s0 = wave * tiles_per_wave * 2, s1 = (s0 + tiles_per_wave * 2 < n_m32 * 2) ? s0 + tiles_per_wave * 2 : n_m32 * 2;
+    if (s0 >= n_m32 * 2) return;
+    const f32x4 *px, *py;
+    auto ptrs = [&](long seg) {
+        seg = seg < s1 ? seg : s1 - 1;
+        const long mt = seg >> 1, p = seg & 1;
+        if (TILED) {            // segment = 24 KB contiguous: [32 rows][768 B]
+            px = mat + seg * 1536 + (lane & 15) * 48 + (lane >> 4);
+            py = px + 16 * 48;
+        } else {
+            px = mat + (mt * 32 + (lane & 15)) * 96 + p * 48 + (lane >> 4);
+            py = px + 16 * 96;
+        }
+    };
+    // unit j: pair j / 2, x or y
+#define KW_LOAD(dst, j) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(((j) & 1) ? py : px), "n"(64 * ((j) / 2)) : "memory")
+    f32x4 a[24];
+    float acc = 0.f;
+    ptrs(s0);
+#pragma unroll
+    for (int j = 0; j < 24; ++j) KW_LOAD(a[j], j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (long seg = s0; seg < s1; ++seg) {
+        ptrs(seg + 1);
+#pragma unroll
+        for (int half = 0; half < 24 / BURST; ++half) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(24 - BURST) : "memory");
+#pragma unroll
+            for (int j = 0; j < BURST; ++j) { asm volatile("" : "+v"(a[half * BURST + j])); acc += a[half * BURST + j].x + a[half * BURST + j].w; }
+#pragma unroll
+            for (int j = 0; j < BURST; j += 2) KW_LOAD(a[half * BURST + j], half * BURST + j);
+#pragma unroll
+            for (int j = 1; j < BURST; j += 2) KW_LOAD(a[half * BURST + j], half * BURST + j);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc == 12345.678f) out[wave] = acc;
+}
+
+template <bool TILED, int BURST>
+static void runwide(const f32x4* d, long n_mtiles, float* out, int blocks_per_cu) {
+    const long n_m32 = n_mtiles / 2;
+    const int lds = blocks_per_cu == 2 ? 72 * 1024 : 150 * 1024;
+    (void)hipFuncSetAttribute((const void*)kwide<TILED, BURST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const long waves = 256L * blocks_per_cu * 4;
+    const long tpw = (n_m32 + waves - 1) / waves;
+    const long used = (n_m32 + tpw - 1) / tpw;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rep = 0; rep < 5; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((kwide<TILED, BURST>), dim3((used + 3) / 4), dim3(256), lds, 0, d, n_m32, tpw, out);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("wide-scan skeleton, %s, refill by %2d, %d waves/SIMD: %.3f ms  %.0f GB/s\n", TILED ? "tiled segments " : "row-major matrix",
+           BURST, blocks_per_cu, best, n_m32 * 49152.0 / best / 1e6);
+    fflush(stdout);
+}
+
 template <int NM>
 static void runmf(const f32x4* d, long n_mtiles, float* out, int blocks_per_cu) {
     const int lds = blocks_per_cu == 2 ? 72 * 1024 : 150 * 1024;
@@ -138,12 +208,29 @@ static void run(const char* name, const f32x4* d, long n_mtiles, float* out, int
     fflush(stdout);
 }
 
+__global__ void fill_random(unsigned* p, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        unsigned x = (unsigned)i * 2654435761u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        p[i] = 0x3c000000u | (x & 0x81ffffffu);       // random sign and mantissa, exponent near 2^-7: finite fp32
+    }
+}
+
 int main(int argc, char** argv) {
     const long rows = argc > 1 ? atol(argv[1]) : 10000000;
     const long n_mtiles = rows / 16;
     f32x4* d; float* out;
     hipMalloc(&d, n_mtiles * 24576L); hipMalloc(&out, 1 << 20);
     hipMemset(d, 0x3c, n_mtiles * 24576L);   // 0x3c3c3c3c = 0.0115 as fp32, 0.0115 as bf16 pairs: finite, non-zero bits
+    if (argc > 3) { hipLaunchKernelGGL(fill_random, dim3(4096), dim3(256), 0, 0, (unsigned*)d, n_mtiles * 6144L); (void)hipDeviceSynchronize(); printf("random matrix bits\n"); }
+    if (argc > 2 && argv[2][0] == 'w') {
+        for (int occ = 2; occ >= 1; --occ) {
+            runwide<false, 12>(d, n_mtiles, out, occ); runwide<true, 12>(d, n_mtiles, out, occ);
+            runwide<false, 2>(d, n_mtiles, out, occ);
+            runwide<false, 24>(d, n_mtiles, out, occ);
+            runwide<false, 6>(d, n_mtiles, out, occ);
+        }
+        return 0;
+    }
     if (argc > 2) {
         for (int occ = 2; occ >= 1; --occ) {
             runmf<0>(d, n_mtiles, out, occ); runmf<1>(d, n_mtiles, out, occ); runmf<2>(d, n_mtiles, out, occ);

@@ -12,7 +12,8 @@ ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=mat.data_ptr(), keepalive=
 ix.dense_topk(np.random.default_rng(0).standard_normal((64, 384)).astype(np.float32), 150)
 names = {0: "full kernel", 16: "full kernel + clock stamps", 48: "stamps, one wave per SIMD", 59: "stamps, 1 wave/SIMD, MFMA+loads only", 1: "no operand split", 2: "no B-fragment reads",
          3: "no split, no B reads", 9: "no split, no lane swap", 11: "MFMAs + ring loads only",
-         15: "ring loads only", 47: "ring loads only, 1 wave/SIMD"}
+         15: "ring loads only", 47: "ring loads only, 1 wave/SIMD", 79: "ring loads only, no epilogue",
+         143: "ring loads only, no LDS fill", 207: "ring loads only, no epilogue, no LDS fill", 64: "full kernel, no epilogue"}
 for v, name in names.items():
     ms = C.c_float()
     _lib.check(lib.rr_debug_scan_x3w(ix.handle, v, 5, C.byref(ms)), "rr_debug_scan_x3w")
