@@ -314,14 +314,16 @@ def main():
         chain = bool(os.environ.get("RR_SCAN_F32_CHAIN"))
         if qpl > 4 and not chain:
             # 5..64 queries per read run on the bf16 matrix cores with exactly-split operands
-            # (rr_dense_x3.hip): 6 (fp32 storage) or 3 (bf16 storage) MFMAs per 32 dims.  Both the HBM
+            # (rr_dense_x3.hip up to 16 queries, rr_dense_x3w.hip beyond): 6 (fp32 storage) or 3 (bf16
+            # storage) MFMA terms per dim.  Both the HBM
             # fraction and the matrix-core fraction are reported; the larger one names the bound.
             terms = 3 if args.dtype == "bf16" else 6
             pf = terms * 2.0 * n_local * DIM * qpl / (avg_ms * 1e-3) / 1e15 if launches else 0.0
             hbm_frac, mfma_frac = achieved / HBM_PEAK_GBS, pf / 2.5
             roof = {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic,
-                    "kernel": f"rr_scan_mfma_x3<{1 if qpl <= 16 else 2 if qpl <= 32 else 4},{args.dtype}>",
+                    "kernel": (f"rr_scan_mfma_x3<1,{args.dtype}>" if qpl <= 16 else
+                               f"rr_scan_x3w<{1 if qpl <= 32 else 2},{args.dtype}>"),
                     "matrix_core_pflops": round(pf, 4), "matrix_core_frac_of_2.5PF": round(mfma_frac, 4)}
             if mfma_frac > hbm_frac:
                 roof.update({"achieved": round(pf * 1e3, 2), "peak": 2500.0, "unit": "TFLOP/s",
