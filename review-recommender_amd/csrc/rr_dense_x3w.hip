@@ -108,7 +108,14 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
     for (int j = 0; j < 24; ++j) RR_X3W_LOAD(a[j], j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    const u32x4* qlane = qs + c * RR_X3W_QSTRIDE + h;     // + (pl * QN + 32 t) * QSTRIDE + 2 * kk
+    // B-fragment addresses: one base register per query plane, every (t, K-step) an immediate offset
+    // (ds_read offsets reach 64 KB; one base for all three planes made hipcc add a literal per read)
+    int qlane[3];                                         // 16-byte unit index into qs
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        qlane[pl] = (pl * QN + c) * RR_X3W_QSTRIDE + h;           // + 32 t * QSTRIDE + 2 * kk
+        asm volatile("" : "+v"(qlane[pl]));                       // (opaque: keeps the three bases apart)
+    }
     float gm[NQ2];
     float2 pend[NQ2];                                     // !STORE: maxima of the M-tile just finished, not yet stored
     float tmax[NQ2];                                      // STORE: running maximum of the 64-row tile
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
     };
     auto read_q = [&](int pl, int t, int kk) {
         if (DBG & 2) kk = 0, pl = 0;
-        return __builtin_bit_cast(bf16x8, qlane[(pl * QN + 32 * t) * RR_X3W_QSTRIDE + 2 * kk]);
+        return __builtin_bit_cast(bf16x8, qs[qlane[pl] + 32 * t * RR_X3W_QSTRIDE + 2 * kk]);
     };
     {   // prologue: K-step 0 of the first segment
         rr_x3w_to_mfma_lanes(a[0], a[1], lo, hi);
@@ -273,7 +280,11 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
                 }
             }
         }
-        if (DBG & 64) continue;                           // (ablation: no epilogue)
+        if (DBG & 64) {                                   // (ablation: no epilogue, the accumulators stay alive)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) asm volatile("" :: "v"(acc[0][e]), "v"(acc[NQ2 - 1][e]));
+            continue;
+        }
         // lane (c, h), register 4g + i: row 8g + 4h + i of the M-tile, query 32t + c
         long long e0 = 0;
         if (DBG & 16) e0 = clock64();
@@ -509,6 +520,10 @@ extern "C" int rr_debug_scan_x3w(rr_index* ix, int32_t dbg, int32_t reps, float*
         case 143: *out_ms = rr_debug_time_x3w<143>(ix, st, reps); break;
         case 207: *out_ms = rr_debug_time_x3w<207>(ix, st, reps); break;
         case 64: *out_ms = rr_debug_time_x3w<64>(ix, st, reps); break;
+        case 32: *out_ms = rr_debug_time_x3w<32>(ix, st, reps); break;
+        case 75: *out_ms = rr_debug_time_x3w<75>(ix, st, reps); break;
+        case 65: *out_ms = rr_debug_time_x3w<65>(ix, st, reps); break;
+        case 66: *out_ms = rr_debug_time_x3w<66>(ix, st, reps); break;
         case 48: *out_ms = rr_debug_time_x3w<48>(ix, st, reps); break;
         case 59: *out_ms = rr_debug_time_x3w<59>(ix, st, reps); break;
         default: RR_REQUIRE(false, "unknown ablation %d", dbg);

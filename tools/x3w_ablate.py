@@ -14,7 +14,11 @@ names = {0: "full kernel", 16: "full kernel + clock stamps", 48: "stamps, one wa
          3: "no split, no B reads", 9: "no split, no lane swap", 11: "MFMAs + ring loads only",
          15: "ring loads only", 47: "ring loads only, 1 wave/SIMD", 79: "ring loads only, no epilogue",
          143: "ring loads only, no LDS fill", 207: "ring loads only, no epilogue, no LDS fill", 64: "full kernel, no epilogue"}
-for v, name in names.items():
+order = list(names) if len(sys.argv) < 3 else [int(a) for a in sys.argv[2].split(",")]
+names[32] = "full kernel, one wave per SIMD"
+names[75] = "MFMAs + ring loads, no epilogue"; names[65] = "no operand split, no epilogue"; names[66] = "no B reads, no epilogue"
+for v in order:
+    name = names[v]
     ms = C.c_float()
     _lib.check(lib.rr_debug_scan_x3w(ix.handle, v, 5, C.byref(ms)), "rr_debug_scan_x3w")
     print(f"variant {v:2d} {name:28s}: {ms.value:.3f} ms  {n * 1536 / ms.value / 1e6:.0f} GB/s", flush=True)
