@@ -9,7 +9,7 @@ import subprocess
 PKG_DIR = pathlib.Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "librr_hip.so"
-SOURCES = ["rr_api.hip", "rr_dense.hip", "rr_dense_bf16.hip", "rr_dense_x3.hip", "rr_dense_x3w.hip", "rr_bm25.hip", "rr_fuse.hip", "rr_reviews.hip"]
+SOURCES = ["rr_api.hip", "rr_dense.hip", "rr_dense_bf16.hip", "rr_dense_x3.hip", "rr_dense_x3w.hip", "rr_dense_flt.hip", "rr_bm25.hip", "rr_fuse.hip", "rr_reviews.hip"]
 # -ffp-contract=off: the BM25 and fusion kernels reproduce numpy's one-rounding-per-
 # operation arithmetic; fused multiply-adds are written out (__builtin_fmaf) where wanted.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",

@@ -61,7 +61,7 @@ extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim
         e = hipEventCreate(&ix->ring0[i]);
         if (e == hipSuccess) e = hipEventCreate(&ix->ring1[i]);
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sel_trace, sizeof(int32_t) * 16 * 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sel_trace, sizeof(int32_t) * 16 * RR_FLT_MAXQ);
     if (e == hipSuccess) e = hipMalloc(&ix->d_qplanes, (size_t)3 * 64 * 384 * 2);
     if (e == hipSuccess) e = hipMalloc(&ix->d_x3, rr_x3_scratch_bytes());
     if (e == hipSuccess) e = hipMalloc(&ix->d_q, sizeof(float) * (size_t)RR_MAX_BATCH * ix->dim_pad);
@@ -104,6 +104,7 @@ extern "C" int rr_index_upload_rows(rr_index* ix, int64_t first_row, int64_t n_r
     int rc = rr_alloc_matrix(ix);
     if (rc) return rc;
     const size_t es = rr_elem_size(ix->dtype);
+    ix->norm_bound = -1.f;
     char* dst = (char*)ix->d_matrix + (size_t)first_row * ix->dim_pad * es;
     if (n_rows)
         RR_HIP_TRY(hipMemcpy2DAsync(dst, es * ix->dim_pad, h_rows, es * ix->dim, es * ix->dim, (size_t)n_rows,
@@ -124,6 +125,7 @@ extern "C" int rr_index_upload_rows_f32(rr_index* ix, int64_t first_row, int64_t
     int rc = rr_alloc_matrix(ix);
     if (rc || n_rows == 0) return rc;
     if (ix->dtype == RR_DTYPE_F32) {
+        ix->norm_bound = -1.f;
         char* dst = (char*)ix->d_matrix + (size_t)first_row * ix->dim_pad * 4;
         RR_HIP_TRY(hipMemcpy2DAsync(dst, 4 * (size_t)ix->dim_pad, h_rows, 4 * (size_t)ix->dim, 4 * (size_t)ix->dim,
                                     (size_t)n_rows, hipMemcpyHostToDevice, ix->stream));
@@ -149,6 +151,7 @@ extern "C" int rr_index_adopt_device(rr_index* ix, const void* d_matrix) {
     RR_HIP_TRY(hipSetDevice(ix->device));
     if (ix->d_matrix && ix->owns_matrix) hipFree(ix->d_matrix);
     ix->d_matrix = const_cast<void*>(d_matrix);
+    ix->norm_bound = -1.f;
     ix->owns_matrix = false;
     return RR_OK;
 }

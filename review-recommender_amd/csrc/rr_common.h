@@ -52,6 +52,8 @@ struct rr_index {
     uint32_t* d_smax = nullptr;  // [qcap][n_super] ordered keys of super-tile maxima
     int32_t scratch_q = 0;
     float* d_q = nullptr;        // staged queries [RR_MAX_BATCH][dim_pad]
+    float norm_bound = -1.f;     // upper bound of the largest row norm; < 0: not computed (any write to the matrix resets it)
+    float delta_bound = 0.f;     // ... and of the largest ||row - bf16(row)||
     int32_t scan_mode = 0;       // RR_SCAN_MODE_* (rr_index_set_scan_mode)
     void* d_x3 = nullptr;        // two-pass selection scratch of the split-operand scan (rr_x3_scratch)
     void* d_qplanes = nullptr;   // [3][64][384] bf16: one launch's queries split in three bf16 terms

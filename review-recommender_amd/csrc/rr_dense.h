@@ -4,7 +4,10 @@
 
 #define RR_SCAN_THREADS 256
 #define RR_MAX_SCAN_WAVES 8192   // 2048 workgroups x 4 waves: upper bound of any resident grid
-#define RR_MFMA_MAXQ 64          // queries per matrix-core scan launch
+#define RR_MFMA_MAXQ 64          // queries per exact matrix-core scan launch
+#define RR_FLT_MAXQ 128          // queries per filter-scan launch (rr_dense_flt.hip)
+#define RR_FLT_NO_BOUND 1000     // rr_dense_chunk_flt: no finite row-norm bound, use the exact scans
+#define RR_FLT_SMALL 1001        // rr_dense_chunk_flt: too few tiles for the filter, use the VALU scans
 
 // Geometry of one scan launch, shared by the scan and the selection.
 struct rr_scan_geom {
@@ -18,7 +21,8 @@ struct rr_scan_geom {
     int64_t n_pad;            // 64 * n_tiles
     int32_t mm_pairs;         // M-tile maxima of the two-pass path: 0 = [tile][Q][4] (rr_scan_mfma_x3),
                               // 1 = [32-row tile][Q][2] (rr_scan_x3w: whole lines per store)
-    int32_t _pad;
+    int32_t gpw;              // groups per wave (0 or 1: the wave's whole run is one group); rr_scan_flt cuts a run into
+    int64_t tiles_per_group;  //   gpw sub-runs of tiles_per_group tiles, group g = wave * gpw + k: fewer tiles to open per group
 };
 
 
@@ -33,16 +37,20 @@ void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int
                       float* d_scores, hipStream_t st, const int32_t* only_if = nullptr);
 // Two-pass selection of the split-operand scan (see rr_select_mtiles in rr_dense.hip).
 #define RR_X3_MCAP 2048          // M-tiles (16 rows) one query may ask to have rescored
-struct rr_x3_scratch {
-    uint32_t* mtiles;            // [RR_MFMA_MAXQ][RR_X3_MCAP] M-tile ids to rescore
-    int32_t* count;              // [RR_MFMA_MAXQ] how many
-    uint32_t* tau;               // [RR_MFMA_MAXQ] key threshold of the query
-    int32_t* fb;                 // [RR_MFMA_MAXQ] 1 = the query needs the stored-score fallback
-    float* sc;                   // [RR_MFMA_MAXQ][RR_X3_MCAP][16] rescored rows
+struct rr_x3_scratch {           // (every array RR_FLT_MAXQ queries long)
+    uint32_t* mtiles;            // [q][RR_X3_MCAP] M-tile ids to rescore
+    int32_t* count;              // [q] how many
+    uint32_t* tau;               // [q] key threshold of the query's rows
+    int32_t* fb;                 // [q] 1 = the query needs the stored-score fallback
+    float* eps;                  // [q] filter scan: error bound of the query's approximate scores
+    float* sc;                   // [q][RR_X3_MCAP][16] rescored rows
 };
 rr_x3_scratch rr_x3_scratch_of(const rr_index* ix);
 size_t rr_x3_scratch_bytes();
-void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st);
+// `eps` (device, per query, may be null): the scan's scores are approximations within eps of the scores
+// the rescoring will produce; M-tiles are then opened down to tau - 2 eps and rows kept down to tau - eps.
+void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st,
+                             const float* eps = nullptr);
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st);
 // Waves a kernel can keep resident on the device (occupancy x CUs x waves per workgroup).
@@ -57,5 +65,9 @@ int rr_l2norm_rows_f32(rr_index* ix, int64_t first_row, int64_t n, float eps, hi
 // split-bf16 matrix-core scan (rr_dense_x3.hip): 5..64 queries, either storage dtype
 int rr_dense_chunk_x3(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                       float* d_scores, hipStream_t st);
+// bf16 filter scan + exact per-row-chain rescoring, 5..128 queries (rr_dense_flt.hip); RR_FLT_NO_BOUND when
+// the matrix has no finite row-norm bound
+int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                       float* d_scores, hipStream_t st);
 // fp32 rows (device, n x dim) -> the index's bf16 matrix rows [first, first + n), optional l2 normalise
 int rr_store_rows_bf16(rr_index* ix, int64_t first_row, int64_t n, float* d_rows_f32, float eps, hipStream_t st);

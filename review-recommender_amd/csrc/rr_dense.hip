@@ -32,7 +32,7 @@
 #define RR_SEL_THREADS 1024
 #define RR_SEL_GCAP 4096    // slow path: tiles kept in LDS
 #define RR_SEL_CCAP 8192    // candidate rows kept in LDS
-#define RR_SEL_LCAP 256     // groups opened by the fast path
+#define RR_SEL_LCAP 1024    // groups opened by the fast path
 
 // ------------------------------------------------------------------ scan
 template <int NF>
@@ -587,9 +587,12 @@ __device__ void rr_rank_sort_desc(const uint64_t* keys, int n, uint64_t* out) {
 // tau = the pool-th largest group maximum (1 = "everything" when there are no more than `pool`
 // groups), and the groups that reach it into list2 (count in counters[0], which may exceed
 // RR_SEL_LCAP: the caller checks).  All threads of the 1024-thread workgroup call this.
+// `open_key` (in/out, optional): on entry nothing; when `eps2` >= 0 the groups are listed down to
+// key(tau - eps2) instead of tau (approximate scores, rr_dense_flt.hip) and that key is returned in it.
 template <typename GroupKeyAt>
 __device__ uint32_t rr_sel_open_groups(GroupKeyAt group_key_at, int ng, int pool, uint32_t (*cnt)[3][16],
-                                       int& phase, uint32_t* counters, uint32_t* list2) {
+                                       int& phase, uint32_t* counters, uint32_t* list2,
+                                       float eps2 = -1.f, uint32_t* open_key = nullptr) {
     const int tid = threadIdx.x;
     uint32_t r[RR_SEL_RK];
     int n_mine = 0;
@@ -609,9 +612,15 @@ __device__ uint32_t rr_sel_open_groups(GroupKeyAt group_key_at, int ng, int pool
         else tau = rr_kth_largest_reg<8>(r, n_mine, (uint32_t)pool, cnt, phase, 7);
     }
     if (tau == 0u) tau = 1u;                           // key 0 marks padding, never a score
+    uint32_t thr = tau;
+    if (eps2 >= 0.f) {
+        thr = rr_f2key(rr_key2f(tau) - eps2);          // (-inf - x = -inf; a NaN bound gives key(NaN): see caller)
+        if (thr == 0u) thr = 1u;
+        if (open_key) *open_key = thr;
+    }
 #pragma unroll
     for (int j = 0; j < RR_SEL_RK; ++j) {
-        if (j < n_mine && r[j] >= tau) {
+        if (j < n_mine && r[j] >= thr) {
             const uint32_t slot = atomicAdd(&counters[0], 1u);
             if (slot < RR_SEL_LCAP) list2[slot] = (uint32_t)(tid + j * RR_SEL_THREADS);
         }
@@ -757,7 +766,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
 __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
     rr_scan_geom G, const float* __restrict__ mmax, const uint32_t* __restrict__ smax, int pool,
     uint32_t* __restrict__ out_mtiles, int32_t* __restrict__ out_count, uint32_t* __restrict__ out_tau,
-    int32_t* __restrict__ fb, int32_t* __restrict__ dbg) {
+    int32_t* __restrict__ fb, int32_t* __restrict__ dbg, const float* __restrict__ eps) {
     __shared__ uint32_t cnt[2][3][16];
     __shared__ uint32_t counters[4];
     __shared__ uint32_t list2[RR_SEL_LCAP];
@@ -765,23 +774,36 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
     const int q = blockIdx.x;
     const int QS = G.qs;
     auto group_key_at = [&](int i) -> uint32_t { return smax[(int64_t)i * QS + q]; };
-    const int ng = G.n_waves;
+    const int gpw = G.gpw > 1 ? G.gpw : 1;
+    const int ng = G.n_waves * gpw;
     int phase = 0;
     if (tid < 4) counters[tid] = 0;
     __syncthreads();
     bool ok = ng <= RR_SEL_RK * RR_SEL_THREADS && ng > pool;   // few groups = a small matrix: take the stored path
-    uint32_t tau = 1u;
+    uint32_t tau = 1u;          // rows are kept down to this key ...
+    uint32_t open = 1u;         // ... M-tiles (and groups) opened down to this one
     if (ok) {
-        tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2);
-        if (counters[0] > RR_SEL_LCAP) ok = false;
+        // approximate scan scores (|s~ - s| <= e): >= pool rows reach tau~ - e, every one of the true
+        // top-pool has s~ >= tau~ - 2e.  2.05 / 1.02: slack for the roundings of this arithmetic itself.
+        const float e = eps ? eps[q] : -1.f;
+        if (eps && !(e >= 0.f && e < 3.0e38f)) ok = false;     // no finite bound for this query
+        if (ok) {
+            tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2, eps ? 2.05f * e : -1.f, &open);
+            if (!eps) open = tau;
+            else tau = rr_f2key(rr_key2f(tau) - 1.02f * e);
+            if (tau == 0u) tau = 1u;
+            if (counters[0] > RR_SEL_LCAP) ok = false;
+        }
     }
     if (ok) {
-        const int C = (int)G.tiles_per_wave;
+        const int C = (int)G.tiles_per_group;
         const int64_t n2 = (int64_t)counters[0] * C;
         const f32x4* mm4 = reinterpret_cast<const f32x4*>(mmax);
         for (int64_t i = tid; i < n2; i += RR_SEL_THREADS) {
-            const int64_t t = (int64_t)list2[i / C] * C + (i % C);
-            if (t >= G.n_tiles) continue;
+            const int g = (int)list2[i / C], k = g % gpw, j = (int)(i % C);
+            const int64_t in_run = (int64_t)k * C + j;                     // tile of the wave's run
+            const int64_t t = (int64_t)(g / gpw) * G.tiles_per_wave + in_run;
+            if (in_run >= G.tiles_per_wave || t >= G.n_tiles) continue;
             float v[4];
             if (G.mm_pairs) {
                 const float2 m0 = reinterpret_cast<const float2*>(mmax)[(2 * t) * QS + q];
@@ -793,7 +815,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
             }
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
-                if (rr_f2key(v[sub]) >= tau) {
+                if (rr_f2key(v[sub]) >= open) {
                     const uint32_t slot = atomicAdd(&counters[1], 1u);
                     if (slot < RR_X3_MCAP) out_mtiles[(int64_t)q * RR_X3_MCAP + slot] = (uint32_t)(t * 4 + sub);
                 }
@@ -871,21 +893,22 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
 rr_x3_scratch rr_x3_scratch_of(const rr_index* ix) {
     rr_x3_scratch s;
     char* p = static_cast<char*>(ix->d_x3);
-    s.mtiles = reinterpret_cast<uint32_t*>(p);  p += sizeof(uint32_t) * RR_MFMA_MAXQ * RR_X3_MCAP;
-    s.count = reinterpret_cast<int32_t*>(p);    p += sizeof(int32_t) * RR_MFMA_MAXQ;
-    s.tau = reinterpret_cast<uint32_t*>(p);     p += sizeof(uint32_t) * RR_MFMA_MAXQ;
-    s.fb = reinterpret_cast<int32_t*>(p);       p += sizeof(int32_t) * RR_MFMA_MAXQ;
+    s.mtiles = reinterpret_cast<uint32_t*>(p);  p += sizeof(uint32_t) * RR_FLT_MAXQ * RR_X3_MCAP;
+    s.count = reinterpret_cast<int32_t*>(p);    p += sizeof(int32_t) * RR_FLT_MAXQ;
+    s.tau = reinterpret_cast<uint32_t*>(p);     p += sizeof(uint32_t) * RR_FLT_MAXQ;
+    s.fb = reinterpret_cast<int32_t*>(p);       p += sizeof(int32_t) * RR_FLT_MAXQ;
+    s.eps = reinterpret_cast<float*>(p);        p += sizeof(float) * RR_FLT_MAXQ;
     s.sc = reinterpret_cast<float*>(p);
     return s;
 }
 size_t rr_x3_scratch_bytes() {
-    return sizeof(uint32_t) * RR_MFMA_MAXQ * RR_X3_MCAP + 3 * sizeof(int32_t) * RR_MFMA_MAXQ +
-           sizeof(float) * (size_t)RR_MFMA_MAXQ * RR_X3_MCAP * 16;
+    return sizeof(uint32_t) * RR_FLT_MAXQ * RR_X3_MCAP + 4 * sizeof(int32_t) * RR_FLT_MAXQ +
+           sizeof(float) * (size_t)RR_FLT_MAXQ * RR_X3_MCAP * 16;
 }
-void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st) {
+void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st, const float* eps) {
     const rr_x3_scratch s = rr_x3_scratch_of(ix);
     hipLaunchKernelGGL(rr_select_mtiles, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_gmax, ix->d_smax, pool,
-                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace);
+                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps);
 }
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st) {
@@ -924,8 +947,10 @@ static int rr_ensure_scratch(rr_index* ix, int nq) {
     ix->scratch_q = 0;
     const size_t groups_cap = (size_t)RR_MAX_SCAN_WAVES;   // one group maximum per scan wave
     RR_HIP_TRY(hipMalloc(&ix->d_sims, sizeof(float) * (size_t)nq * n_tiles * 64));
-    RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * (size_t)nq * n_tiles * 4));   // x4: per-M-tile maxima of the split-operand scan
-    RR_HIP_TRY(hipMalloc(&ix->d_smax, sizeof(uint32_t) * (size_t)nq * groups_cap));
+    // tile / group maxima: up to RR_FLT_MAXQ queries per launch (x4: per-M-tile maxima of the matrix-core scans)
+    const size_t nm = nq >= RR_MFMA_MAXQ ? RR_FLT_MAXQ : nq;
+    RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * nm * n_tiles * 4));
+    RR_HIP_TRY(hipMalloc(&ix->d_smax, sizeof(uint32_t) * nm * groups_cap));
     ix->scratch_q = nq;
     return RR_OK;
 }
@@ -955,7 +980,8 @@ rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks) {
     G.n_waves = (int32_t)((G.n_tiles + G.tiles_per_wave - 1) / G.tiles_per_wave);
     G.qs = 0;
     G.mm_pairs = 0;
-    G._pad = 0;
+    G.gpw = 1;
+    G.tiles_per_group = G.tiles_per_wave;
     return G;
 }
 
@@ -1071,6 +1097,7 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
     // batches run on the bf16 matrix cores with exactly-split operands (rr_dense_x3.hip);
     // RR_SCAN_F32_CHAIN=1 selects the f32-input MFMA kernels (scores = pure fmaf chains) instead
     static const bool f32_chain = getenv("RR_SCAN_F32_CHAIN") != nullptr;
+    static const bool exact_scan = getenv("RR_SCAN_EXACT") != nullptr;
     // measured crossover (10M rows): the per-row-chain VALU scans win up to 4 queries per read
     // (2.4-2.5 ms fp32, 1.3-1.5 ms bf16); from 5 on the matrix-core scan does (2.7-2.9 / 1.8 ms
     // for up to 16 queries, against 3.0 / 2.4 ms for the 8-query VALU scan)
@@ -1084,17 +1111,34 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
         int64_t* rows = d_rows + (int64_t)q0 * pool;
         float* scores = d_scores + (int64_t)q0 * pool;
         int n;
-        if (mfma_ok && left > valu_max) {
-            // 5..64 queries share one read of the matrix on the matrix cores
+        bool small = false;        // the filter path declined: too few tiles
+        if (mfma_ok && left > valu_max && !f32_chain && !exact_scan && ix->scan_mode == RR_SCAN_MODE_DEFAULT &&
+            (ix->n_rows + 63) / 64 < 8 * (int64_t)pool)
+            small = true;
+        if (mfma_ok && left > valu_max && !small) {
+            // 5..128 queries share one read of the matrix: bf16 filter scan + exact rescoring of the
+            // candidates (rr_dense_flt.hip); without a finite row-norm bound, or with RR_SCAN_EXACT=1 /
+            // RR_SCAN_MODE_STORED, the exact split-operand scans, 64 queries per read
             n = left < RR_MFMA_MAXQ ? left : RR_MFMA_MAXQ;
-            if (!f32_chain) rc = rr_dense_chunk_x3(ix, q, n, pool, rows, scores, st);
+            bool done = false;
+            if (!f32_chain && !exact_scan && ix->scan_mode == RR_SCAN_MODE_DEFAULT) {
+                const int nf = left < RR_FLT_MAXQ ? left : RR_FLT_MAXQ;
+                rc = rr_dense_chunk_flt(ix, q, nf, pool, rows, scores, st);
+                if (rc != RR_FLT_NO_BOUND && rc != RR_FLT_SMALL) {
+                    done = true;
+                    n = nf;
+                }
+            }
+            if (done) {
+            } else if (!f32_chain) rc = rr_dense_chunk_x3(ix, q, n, pool, rows, scores, st);
             else if (bf16) rc = rr_dense_chunk_mfma_bf16(ix, q, n, pool, rows, scores, st);
             else if (n <= 16) rc = rr_dense_chunk_mfma<1>(ix, q, n, pool, rows, scores, st);
             else if (n <= 32) rc = rr_dense_chunk_mfma<2>(ix, q, n, pool, rows, scores, st);
             else rc = rr_dense_chunk_mfma<4>(ix, q, n, pool, rows, scores, st);
         } else {
             // the VALU scan kernels read NB = 1/2/4/8 query slots; slots past n hold zeros
-            n = left < valu_max ? left : valu_max;
+            const int vmax = small ? 8 : valu_max;
+            n = left < vmax ? left : vmax;
             rc = bf16 ? rr_dense_chunk_bf16(ix, q, n, pool, rows, scores, st)
                       : rr_dense_chunk(ix, q, n, pool, rows, scores, st, q0 == 0);
         }
@@ -1231,6 +1275,7 @@ extern "C" int rr_index_l2_normalize(rr_index* ix, float eps) {
                "rr_index_l2_normalize: a bf16 index is normalised in fp32 before rounding (rr_index_upload_rows_f32)");
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
+    ix->norm_bound = -1.f;
     const int rows_per_block = 4;
     const unsigned grid = (unsigned)((ix->n_rows + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(rr_l2norm_f32, dim3(grid), dim3(64 * rows_per_block), 0, ix->stream,

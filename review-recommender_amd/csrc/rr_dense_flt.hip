@@ -1,0 +1,464 @@
+// rr_dense_flt.hip -- K1 batched scan, 5..128 queries per matrix read: bf16 FILTER scan + exact rescoring.
+//
+// The split-operand scans (rr_dense_x3*.hip) compute every one of the 10M x B scores to fp32
+// accuracy on the matrix cores and are paced by that arithmetic (6 MFMA terms + a 48-op operand
+// split per 32 rows x 16 dims), not by HBM.  But only ~pool rows per query survive, and the
+// selection already rescans its candidates.  So the scan only has to be a FILTER with a known
+// error bound:
+//
+//   s~(row) = sum_k bf16(a_k) * bf16(q_k)          one bf16 MFMA term, rounding to nearest even
+//   |s~ - s| <= eps_q = 2^-7 (1 + margin) * max_row ||a|| * ||q||     (bf16 unit roundoff 2^-8 on each
+//                       factor, Cauchy-Schwarz; bf16 storage: 2^-8, the row is exact)
+//
+//   tau~  = pool-th largest group maximum of s~   =>  >= pool rows have s >= tau~ - eps
+//   every true top-pool row has s >= tau~ - eps, hence s~ >= tau~ - 2 eps
+//   => the 16-row M-tiles whose s~ maximum reaches tau~ - 2 eps contain the exact top-pool.
+//
+// Those M-tiles (~pool + a few: the score density at the cut is ~1e4 rows per unit score at 10M
+// rows) are rescored by rr_rescore_chain with THE PER-ROW FMAF CHAIN OF THE SINGLE-QUERY SCAN
+// (rr_scan_f32 / rr_scan_bf16: 16 lanes per row, fixed DPP sum), rows below tau~ - eps are dropped
+// and the rest ordered by (score desc, row asc).  The result is the exact top-pool of the
+// per-row-chain scores: a query's answer is bitwise the same alone, in any batch, on any shard.
+// A query whose candidate lists overflow (eps too loose for its score density, massive ties, tiny
+// matrices) raises its flag and is served by the stored-score pass of rr_dense_x3w.hip instead.
+//
+// The scan itself is rr_scan_x3w's stream with one MFMA term: 32x32x16 tiles, 16-rows x 64-B load
+// instructions turned into MFMA lanes by v_permlane16_swap, a 24-unit register ring refilled by
+// halves in bursts, M-tile maxima stored one M-tile late behind the next burst, software pipeline
+// pinned with sched_barrier.  Per 32-row K-step: NQ2 MFMAs, 4 lane swaps + 4 v_cvt_pk_bf16_f32;
+// one query plane of 768 B in LDS, so 128 queries fit (98 KB): a quarter of the matrix reads of
+// the 64-query kernels at batch 256.
+#include "rr_x3.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define RR_FLT_QSTRIDE 49   // 16-B units per query in LDS: 48 + 1 pad (eight consecutive queries, eight bank groups)
+
+// One workgroup (64 lanes) per query slot: the bf16 plane (round to nearest even) in the k order the
+// scan's A fragments imply, and the slot's error bound (see rr_flt_bounds).
+struct rr_flt_bounds {
+    float row_norm;      // >= max over rows ||a||
+    float row_delta;     // >= max over rows ||a - bf16(a)||   (0 for a bf16 matrix)
+};
+__global__ __launch_bounds__(64) void rr_flt_prep_queries(const float* __restrict__ q, unsigned short* __restrict__ plane,
+                                                          float* __restrict__ eps, rr_flt_bounds B, int order) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const float* src = q + (int64_t)slot * 384;
+    float ss = 0.f, sr = 0.f, sd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pos = lane + 64 * i;
+        int from = pos;
+        if (order == RR_X3_ORDER_WIDE_BF16) {
+            const int e = pos & 31, v = e >> 4, h = (e >> 3) & 1, j = e & 7;
+            from = (pos & ~31) + 16 * h + 8 * v + j;
+        }
+        const float x = src[from];
+        const __bf16 r = (__bf16)x;                                // round to nearest even
+        const float xr = (float)r, d = x - xr;
+        ss = __builtin_fmaf(x, x, ss);
+        sr = __builtin_fmaf(xr, xr, sr);
+        sd = __builtin_fmaf(d, d, sd);
+        plane[(int64_t)slot * 384 + pos] = __builtin_bit_cast(unsigned short, r);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        ss += __shfl_xor(ss, m, 64);
+        sr += __shfl_xor(sr, m, 64);
+        sd += __shfl_xor(sd, m, 64);
+    }
+    // s~ - s = sum (a~ - a) q~ + sum a (q~ - q): |.| <= ||a - a~|| ||q~|| + ||a|| ||q - q~||  (Cauchy-Schwarz, twice);
+    // + 2^-14 ||a|| ||q|| for the fp32 accumulations of the scan and of the rescoring chain (384 terms each);
+    // 1 % on top for the roundings of these norms themselves.  NaN / inf anywhere gives a NaN / inf bound: no filtering.
+    if (lane == 0)
+        eps[slot] = 1.01f * (B.row_delta * sqrtf(sr) + B.row_norm * sqrtf(sd) + 6.1035156e-5f * B.row_norm * sqrtf(ss));
+}
+
+// max over rows of ||a|| and of ||a - bf16(a)||, as the bits of non-negative floats (atomicMax on uint).
+// 16 lanes per row, 16-byte loads (four rows per wave instruction), 64 rows per wave.
+template <bool A_BF16>
+__global__ __launch_bounds__(256) void rr_row_norm_max(const void* __restrict__ mat, int64_t n_rows, int dim_pad,
+                                                       unsigned int* __restrict__ out) {
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 64;
+    const int units = dim_pad / (A_BF16 ? 8 : 4);            // 16-byte units per row
+    float best = 0.f, bestd = 0.f;
+    for (int it = 0; it < 16; ++it) {
+        const int64_t row = row0 + 4 * it + grp;
+        float ss = 0.f, sd = 0.f;
+        if (row < n_rows) {
+            const u32x4* p = static_cast<const u32x4*>(mat) + row * units;
+            for (int u = sub; u < units; u += 16) {
+                const u32x4 w = p[u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (A_BF16) {
+                        const float x0 = __uint_as_float(w[e] << 16), x1 = __uint_as_float(w[e] & 0xFFFF0000u);
+                        ss = __builtin_fmaf(x0, x0, ss);
+                        ss = __builtin_fmaf(x1, x1, ss);
+                    } else {
+                        const float x = __uint_as_float(w[e]);
+                        const float d = x - (float)(__bf16)x;
+                        ss = __builtin_fmaf(x, x, ss);
+                        sd = __builtin_fmaf(d, d, sd);
+                    }
+                }
+            }
+        }
+        ss = rr_row16_sum(ss);
+        sd = rr_row16_sum(sd);
+        best = fmaxf(best, (ss == ss) ? sqrtf(ss) : INFINITY);       // a NaN row: no finite bound
+        bestd = fmaxf(bestd, (sd == sd) ? sqrtf(sd) : INFINITY);
+    }
+    best = rr_wave_max(best);
+    bestd = rr_wave_max(bestd);
+    if (lane == 0) {
+        atomicMax(out, __float_as_uint(best));
+        atomicMax(out + 1, __float_as_uint(bestd));
+    }
+}
+
+// ------------------------------------------------------------------ the filter scan
+template <int NQ2, bool A_BF16>
+__global__ __launch_bounds__(512, 2) void rr_scan_flt(
+    const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [32*NQ2][48] units
+    float* __restrict__ gmax, uint32_t* __restrict__ smax) {
+    constexpr int THREADS = 512;
+    constexpr int QN = 32 * NQ2;
+    constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
+    constexpr int SEGS = A_BF16 ? 1 : 2;              // ring segments (24 units per lane) per 32-row M-tile
+    constexpr int STEPS = A_BF16 ? 24 : 12;           // K-steps (16 dims) per ring segment
+    __shared__ u32x4 qs[QN * RR_FLT_QSTRIDE];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < QN * RR_X3_UNITS; i += THREADS)
+        qs[(i / RR_X3_UNITS) * RR_FLT_QSTRIDE + (i % RR_X3_UNITS)] = plane[i];
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int c = lane & 31;                          // MFMA: A row / B and C column
+    const int h = lane >> 5;                          //       k half (A, B); C rows 8g + 4h + i
+    const int64_t wave = (int64_t)blockIdx.x * (THREADS / 64) + (tid >> 6);
+    if (wave >= G.n_waves) return;
+    const int64_t t0 = wave * G.tiles_per_wave;
+    const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
+    const int64_t m0 = t0 * 2, m1 = t1 * 2;           // 32-row M-tiles of this wave
+
+    const int lrow = lane & 15, lpc = lane >> 4;      // load order: row of the 16-row half, 16-B piece
+    const u32x4* px;
+    const u32x4* py;
+    auto seg_ptrs = [&](int64_t seg) {                // segment = (M-tile, ring segment of its rows), linear
+        int64_t mt = m0 + seg / SEGS;
+        const int p = (int)(seg % SEGS);
+        mt = mt < m1 ? mt : m1 - 1;                   // (past the end: redundant re-loads, never used)
+        int64_t rx = mt * 32 + lrow, ry = rx + 16;
+        rx = rx < G.n_rows ? rx : G.n_rows - 1;
+        ry = ry < G.n_rows ? ry : G.n_rows - 1;
+        px = mat + rx * ROWU + p * 48 + lpc;
+        py = mat + ry * ROWU + p * 48 + lpc;
+    };
+#define RR_FLT_LOAD(dst, j) \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(((j) & 1) ? py : px), "n"(64 * ((j) / 2)) : "memory")
+    u32x4 a[24];
+    seg_ptrs(0);
+#pragma unroll
+    for (int j = 0; j < 24; ++j) RR_FLT_LOAD(a[j], j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    int qlane = c * RR_FLT_QSTRIDE + h;               // 16-byte unit index into qs: + 32 t * QSTRIDE + 2 * kk
+    float gm[NQ2];                                    // running maximum of the current group (sub-run of tiles)
+    float2 pend[NQ2];                                 // maxima of the M-tile just finished, stored one M-tile late,
+    uint32_t pend_key[NQ2];                           // ... with the group's running maximum (the last store wins)
+    int64_t pend_group = wave * G.gpw;
+#pragma unroll
+    for (int t = 0; t < NQ2; ++t) {
+        gm[t] = -INFINITY;
+        pend[t] = float2{-INFINITY, -INFINITY};
+        pend_key[t] = 0u;
+    }
+    auto read_q = [&](int t, int kk) { return __builtin_bit_cast(bf16x8, qs[qlane + 32 * t * RR_FLT_QSTRIDE + 2 * kk]); };
+    // fp32 pair (lo, hi = dims 8h .. 8h+7 of the K-step) -> one bf16x8 operand, round to nearest even
+    auto cvt_op = [&](int k, const u32x4& lo, const u32x4& hi, u32x4& out) {
+        const float x0 = __uint_as_float(k < 2 ? lo[2 * k] : hi[2 * k - 4]);
+        const float x1 = __uint_as_float(k < 2 ? lo[2 * k + 1] : hi[2 * k - 3]);
+        const bf16x2 r = bf16x2{(__bf16)x0, (__bf16)x1};
+        out[k] = __builtin_bit_cast(unsigned int, r);
+    };
+    // ---- software pipeline (see rr_dense_x3w.hip): during the NQ2 MFMAs of K-step s the vector issue
+    // prepares K-step s + 1: 4 lane swaps + 4 packed conversions (fp32 matrix) and NQ2 ds_reads.
+    constexpr int NV = A_BF16 ? 4 : 8;
+    constexpr int VPS = (NV + NQ2 - 1) / NQ2;
+    u32x4 lo, hi, nxt;             // the pair being prepared (MFMA lanes) and its bf16 operand
+    bf16x8 af;                     // operand of the current K-step
+    bf16x8 qf[2][NQ2];             // B fragments, two K-steps
+    auto valu_op = [&](int k, const u32x4& x, const u32x4& y) {
+        if (k < 4) {
+            const auto r = __builtin_amdgcn_permlane16_swap(x[k], y[k], false, false);
+            lo[k] = r[0];
+            hi[k] = r[1];
+        } else if (!A_BF16 && k < 8) {
+            cvt_op(k - 4, lo, hi, nxt);
+        }
+    };
+    {   // prologue: K-step 0 of the first segment
+#pragma unroll
+        for (int k = 0; k < 8; ++k) valu_op(k, a[0], a[1]);
+        af = __builtin_bit_cast(bf16x8, A_BF16 ? lo : nxt);
+#pragma unroll
+        for (int t = 0; t < NQ2; ++t) qf[0][t] = read_q(t, 0);
+    }
+
+#pragma unroll 1
+    for (int64_t mt = m0; mt < m1; ++mt) {
+        f32x16 acc[NQ2];
+#pragma unroll
+        for (int t = 0; t < NQ2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+        for (int p = 0; p < SEGS; ++p) {
+            seg_ptrs((mt - m0) * SEGS + p + 1);           // the bursts of this segment refill the ring for the next
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                const int cb = (p * STEPS + s) & 1;
+                const int s2 = (s + 1) % STEPS;                           // the K-step being prepared
+                const int kk2 = A_BF16 ? s2 : (12 * p + s + 1) % 24;      // ... as K-step of the row
+                const bool swap = A_BF16 ? (s2 % 2 == 0) : true;          // it starts a new pair of the ring
+                const int np = A_BF16 ? s2 / 2 : s2;
+                constexpr int REFILL_SLOT = 3 / VPS;                      // the slot that issues the last lane swap
+                if (swap && (np == 6 || np == 0)) {
+                    // ring waits and deferred maxima stores exactly as in rr_scan_x3w
+                    if (p == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + 2 * NQ2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(a[(np / 6) * 12 + j]));
+                }
+#pragma unroll
+                for (int j = 0; j < NQ2; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[cb][j], acc[j], 0, 0, 0);
+                    if (swap) {
+#pragma unroll
+                        for (int k = VPS * j; k < VPS * j + VPS; ++k) valu_op(k, a[2 * np], a[2 * np + 1]);
+                    }
+                    qf[cb ^ 1][j] = read_q(j, kk2);
+                    if (swap && (np == 5 || np == 11) && j == REFILL_SLOT) {
+                        // the lane swaps of this half's last pair are issued: re-load the half
+#pragma unroll
+                        for (int u = 0; u < 12; u += 2) RR_FLT_LOAD(a[(np / 6) * 12 + u], (np / 6) * 12 + u);
+#pragma unroll
+                        for (int u = 1; u < 12; u += 2) RR_FLT_LOAD(a[(np / 6) * 12 + u], (np / 6) * 12 + u);
+                        if (p == 0 && np == 5) {
+                            // 2 NQ2 stores, always (the ring waits count them): the previous M-tile's maxima and
+                            // its group's running maximum.  First M-tile of the wave: nothing pending -- the
+                            // stores go to its own slots, overwritten by this wave one M-tile later.
+                            const int64_t mprev = mt > m0 ? mt - 1 : mt;
+#pragma unroll
+                            for (int t = 0; t < NQ2; ++t)
+                                if (h == 0) {
+                                    *reinterpret_cast<float2*>(gmax + ((mprev * QN + 32 * t + c) << 1)) = pend[t];
+                                    smax[pend_group * QN + 32 * t + c] = pend_key[t];
+                                }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (A_BF16) af = __builtin_bit_cast(bf16x8, (s2 % 2 == 0) ? lo : hi);
+                else af = __builtin_bit_cast(bf16x8, nxt);
+            }
+        }
+        // lane (c, h), register 4g + i: row 8g + 4h + i of the M-tile, query 32t + c
+        const int64_t rbase = mt * 32 + 4 * h;
+        const bool full = mt * 32 + 32 <= G.n_rows;
+#pragma unroll
+        for (int t = 0; t < NQ2; ++t) {
+            float m16[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                if (!full) v = rr_x3_canon(v, rbase + 8 * g, G.n_rows);            // (fmaxf drops a NaN by itself)
+                m16[g >> 1] = fmaxf(m16[g >> 1], fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
+            const auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m16[0]), __float_as_uint(m16[0]), false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m16[1]), __float_as_uint(m16[1]), false, false);
+            m16[0] = fmaxf(__uint_as_float(r0[0]), __uint_as_float(r0[1]));
+            m16[1] = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+            gm[t] = fmaxf(gm[t], fmaxf(m16[0], m16[1]));
+            pend[t] = float2{m16[0], m16[1]};
+            pend_key[t] = rr_f2key(gm[t]);
+        }
+        {   // group k of the wave = tiles [t0 + k Cg, t0 + (k + 1) Cg) of its run
+            const int in_run = (int)((mt >> 1) - t0), cg = (int)G.tiles_per_group;
+            pend_group = wave * G.gpw + in_run / cg;
+            if ((mt & 1) == 1 && (in_run + 1) % cg == 0) {
+#pragma unroll
+                for (int t = 0; t < NQ2; ++t) gm[t] = -INFINITY;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
+    if (h == 0) {
+#pragma unroll
+        for (int t = 0; t < NQ2; ++t) {
+            *reinterpret_cast<float2*>(gmax + (((m1 - 1) * QN + 32 * t + c) << 1)) = pend[t];
+            smax[pend_group * QN + 32 * t + c] = pend_key[t];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ exact rescoring
+// One wave per (query, listed 16-row M-tile): the single-query scans' per-row arithmetic -- lane j of
+// a 16-lane row takes 16-byte units j, j + 16, ... of the row, one fmaf chain over its 24 elements in
+// ascending order, rr_row16_sum over the row (rr_scan_f32<6,1> / rr_scan_bf16<1>).  sc[query][slot][16].
+template <bool A_BF16>
+__global__ __launch_bounds__(256) void rr_rescore_chain(
+    const void* __restrict__ mat, int64_t n_rows, const float* __restrict__ queries,   // [nq][384] fp32, padded
+    const uint32_t* __restrict__ mtiles, const int32_t* __restrict__ count, const int32_t* __restrict__ fb,
+    float* __restrict__ sc) {
+    const int q = blockIdx.y;
+    if (fb[q]) return;
+    const int n = count[q];
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 15, grp = lane >> 4;
+    const f32x4* qv = reinterpret_cast<const f32x4*>(queries + (int64_t)q * 384);
+    f32x4 qreg[6];
+    if (A_BF16) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            qreg[2 * i] = qv[2 * (sub + 16 * i)];
+            qreg[2 * i + 1] = qv[2 * (sub + 16 * i) + 1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) qreg[i] = qv[16 * i + sub];
+    }
+    for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n; slot += gridDim.x * 4) {
+        const int64_t m16 = mtiles[(int64_t)q * RR_X3_MCAP + slot];
+        float mine = 0.f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                   // four rows per step: lane (sub, grp) -> row 4 it + grp
+            int64_t row = m16 * 16 + 4 * it + grp;
+            row = row < n_rows ? row : n_rows - 1;
+            float acc = 0.f;
+            if (A_BF16) {
+                const u32x4* p = static_cast<const u32x4*>(mat) + row * 48 + sub;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const u32x4 x = p[16 * i];
+                    const f32x4 q0 = qreg[2 * i], q1 = qreg[2 * i + 1];
+                    acc = __builtin_fmaf(__uint_as_float(x.x << 16), q0.x, acc);
+                    acc = __builtin_fmaf(__uint_as_float(x.x & 0xFFFF0000u), q0.y, acc);
+                    acc = __builtin_fmaf(__uint_as_float(x.y << 16), q0.z, acc);
+                    acc = __builtin_fmaf(__uint_as_float(x.y & 0xFFFF0000u), q0.w, acc);
+                    acc = __builtin_fmaf(__uint_as_float(x.z << 16), q1.x, acc);
+                    acc = __builtin_fmaf(__uint_as_float(x.z & 0xFFFF0000u), q1.y, acc);
+                    acc = __builtin_fmaf(__uint_as_float(x.w << 16), q1.z, acc);
+                    acc = __builtin_fmaf(__uint_as_float(x.w & 0xFFFF0000u), q1.w, acc);
+                }
+            } else {
+                const f32x4* p = static_cast<const f32x4*>(mat) + row * 96 + sub;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const f32x4 x = p[16 * i];
+                    acc = __builtin_fmaf(x.x, qreg[i].x, acc);
+                    acc = __builtin_fmaf(x.y, qreg[i].y, acc);
+                    acc = __builtin_fmaf(x.z, qreg[i].z, acc);
+                    acc = __builtin_fmaf(x.w, qreg[i].w, acc);
+                }
+            }
+            acc = rr_row16_sum(acc);
+            mine = (sub == it) ? acc : mine;               // lane (sub, grp) keeps row 4 sub + grp (sub < 4)
+        }
+        if (sub < 4) {
+            const int r = 4 * sub + grp;
+            const int64_t row = m16 * 16 + r;
+            const float v = (row < n_rows && mine == mine) ? mine : -INFINITY;   // NaN scores and pad rows rank last
+            sc[((int64_t)q * RR_X3_MCAP + slot) * 16 + r] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static int rr_flt_get_bounds(rr_index* ix, hipStream_t st, rr_flt_bounds* out) {
+    if (ix->norm_bound < 0.f) {
+        unsigned int* d = reinterpret_cast<unsigned int*>(rr_x3_scratch_of(ix).eps);   // borrowed for two words
+        RR_HIP_TRY(hipMemsetAsync(d, 0, 2 * sizeof(unsigned int), st));
+        const unsigned blocks = (unsigned)((ix->n_rows + 255) / 256);
+        if (ix->dtype == RR_DTYPE_BF16)
+            hipLaunchKernelGGL((rr_row_norm_max<true>), dim3(blocks), dim3(256), 0, st, ix->d_matrix, ix->n_rows, ix->dim_pad, d);
+        else
+            hipLaunchKernelGGL((rr_row_norm_max<false>), dim3(blocks), dim3(256), 0, st, ix->d_matrix, ix->n_rows, ix->dim_pad, d);
+        unsigned int bits[2] = {0u, 0u};
+        RR_HIP_TRY(hipMemcpyAsync(bits, d, sizeof(bits), hipMemcpyDeviceToHost, st));
+        RR_HIP_TRY(hipStreamSynchronize(st));
+        float nb[2];
+        memcpy(nb, bits, sizeof(nb));
+        ix->norm_bound = nb[0] * 1.0001f;
+        ix->delta_bound = nb[1] * 1.0001f;
+    }
+    out->row_norm = ix->norm_bound;
+    out->row_delta = ix->delta_bound;
+    return RR_OK;
+}
+
+template <int NQ2, bool A_BF16>
+static int rr_dense_chunk_flt_t(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                                float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
+    constexpr int THREADS = 512;
+    constexpr int QN = 32 * NQ2;
+    static int waves = 0;
+    if (!waves) waves = rr_resident_waves((const void*)rr_scan_flt<NQ2, A_BF16>, THREADS, ix->device);
+    rr_scan_geom G = rr_make_geom(ix, waves / 4);
+    G.qs = QN;
+    G.mm_pairs = 1;
+    // selection groups = quarter runs: ~4x fewer tile maxima to open per group (at most 8192 groups)
+    G.gpw = RR_MAX_SCAN_WAVES / G.n_waves < 4 ? (RR_MAX_SCAN_WAVES / G.n_waves < 1 ? 1 : RR_MAX_SCAN_WAVES / G.n_waves) : 4;
+    if (G.gpw > G.tiles_per_wave) G.gpw = (int32_t)G.tiles_per_wave;
+    G.tiles_per_group = (G.tiles_per_wave + G.gpw - 1) / G.gpw;
+    G.gpw = (int32_t)((G.tiles_per_wave + G.tiles_per_group - 1) / G.tiles_per_group);     // no empty trailing groups
+    unsigned short* plane = reinterpret_cast<unsigned short*>(ix->d_qplanes);
+    const rr_x3_scratch X = rr_x3_scratch_of(ix);
+    RR_HIP_TRY(hipMemsetAsync(ix->d_smax, 0, sizeof(uint32_t) * (size_t)G.n_waves * G.gpw * QN, st));   // (empty groups: key 0)
+    hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, X.eps, bounds,
+                       A_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL);
+    const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
+    const int slot = rr_scan_events_begin(ix, st);
+    hipLaunchKernelGGL((rr_scan_flt<NQ2, A_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
+                       reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax);
+    rr_scan_events_end(ix, slot, st);
+    rr_launch_select_mtiles(ix, G, nq, pool, st, X.eps);
+    hipLaunchKernelGGL((rr_rescore_chain<A_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
+                       X.mtiles, X.count, X.fb, X.sc);
+    rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st);
+    RR_HIP_TRY(hipGetLastError());
+    // Flagged queries: the stored-score pass of the split-operand scan, 64 queries at a time; every
+    // launch in it returns at once when no flag of its queries is up.
+    for (int q0 = 0; q0 < nq; q0 += RR_MFMA_MAXQ) {
+        const int n = nq - q0 < RR_MFMA_MAXQ ? nq - q0 : RR_MFMA_MAXQ;
+        const int rc = rr_dense_chunk_x3w_fallback(ix, d_q + (int64_t)q0 * ix->dim_pad, n, pool, d_rows + (int64_t)q0 * pool,
+                                                   d_scores + (int64_t)q0 * pool, X.fb + q0, st);
+        if (rc != RR_OK) return rc;
+    }
+    return RR_OK;
+}
+
+int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                       float* d_scores, hipStream_t st) {
+    // A small matrix has too few tile groups for the threshold to mean anything (every query would be
+    // flagged): the caller runs the per-row-chain VALU scans instead, which cost microseconds there and
+    // keep the answer bitwise equal to what a large index (or the unsharded one) gives through rescoring.
+    if ((ix->n_rows + 63) / 64 < 8 * (int64_t)pool) return RR_FLT_SMALL;
+    rr_flt_bounds nb;
+    const int rc = rr_flt_get_bounds(ix, st, &nb);
+    if (rc != RR_OK) return rc;
+    if (!(nb.row_norm < 3.0e18f))     // no usable bound (inf / NaN rows, or squares that overflow): exact scans, 64 at a time
+        return RR_FLT_NO_BOUND;
+    const bool b = ix->dtype == RR_DTYPE_BF16;
+    if (nq <= 32)
+        return b ? rr_dense_chunk_flt_t<1, true>(ix, d_q, nq, pool, d_rows, d_scores, nb, st)
+                 : rr_dense_chunk_flt_t<1, false>(ix, d_q, nq, pool, d_rows, d_scores, nb, st);
+    if (nq <= 64)
+        return b ? rr_dense_chunk_flt_t<2, true>(ix, d_q, nq, pool, d_rows, d_scores, nb, st)
+                 : rr_dense_chunk_flt_t<2, false>(ix, d_q, nq, pool, d_rows, d_scores, nb, st);
+    return b ? rr_dense_chunk_flt_t<4, true>(ix, d_q, nq, pool, d_rows, d_scores, nb, st)
+             : rr_dense_chunk_flt_t<4, false>(ix, d_q, nq, pool, d_rows, d_scores, nb, st);
+}

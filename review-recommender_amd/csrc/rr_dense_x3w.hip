@@ -449,6 +449,35 @@ static int rr_dense_chunk_x3w_t(rr_index* ix, const float* d_q, int nq, int pool
     return RR_OK;
 }
 
+template <int NQ2, bool A_BF16>
+static int rr_x3w_fallback_t(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                             float* d_scores, const int32_t* flags, hipStream_t st) {
+    constexpr int THREADS = NQ2 == 2 ? 512 : 256;
+    constexpr int QN = 32 * NQ2;
+    static int waves = 0;
+    if (!waves) waves = rr_resident_waves((const void*)rr_scan_x3w<NQ2, A_BF16, true>, THREADS, ix->device);
+    rr_scan_geom G = rr_make_geom(ix, waves / 4);
+    G.qs = QN;
+    unsigned short* planes = reinterpret_cast<unsigned short*>(ix->d_qplanes);
+    const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
+    rr_launch_split_queries(d_q, planes, QN, A_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL, st);
+    hipLaunchKernelGGL((rr_scan_x3w<NQ2, A_BF16, true>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
+                       reinterpret_cast<const u32x4*>(planes), ix->d_sims, ix->d_gmax, ix->d_smax, flags, nq);
+    rr_launch_select(ix, G, nq, pool, d_rows, d_scores, st, flags);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_dense_chunk_x3w_fallback(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                                float* d_scores, const int32_t* flags, hipStream_t st) {
+    const bool b = ix->dtype == RR_DTYPE_BF16;
+    if (nq <= 32)
+        return b ? rr_x3w_fallback_t<1, true>(ix, d_q, nq, pool, d_rows, d_scores, flags, st)
+                 : rr_x3w_fallback_t<1, false>(ix, d_q, nq, pool, d_rows, d_scores, flags, st);
+    return b ? rr_x3w_fallback_t<2, true>(ix, d_q, nq, pool, d_rows, d_scores, flags, st)
+             : rr_x3w_fallback_t<2, false>(ix, d_q, nq, pool, d_rows, d_scores, flags, st);
+}
+
 int rr_dense_chunk_x3w(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                        float* d_scores, hipStream_t st) {
     const bool b = ix->dtype == RR_DTYPE_BF16;

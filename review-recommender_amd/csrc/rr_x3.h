@@ -64,6 +64,11 @@ bool rr_x3_stored_path(const rr_index* ix);
 int rr_dense_chunk_x3w(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                        float* d_scores, hipStream_t st);
 
+// Stored-score pass of rr_scan_x3w + rr_select for the queries (<= 64) whose flag in `flags` is up;
+// every launch in it returns at once when none is.
+int rr_dense_chunk_x3w_fallback(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                                float* d_scores, const int32_t* flags, hipStream_t st);
+
 // NaN scores and pad rows rank last (rows row0 .. row0+3 of one query)
 __device__ __forceinline__ f32x4 rr_x3_canon(f32x4 v, int64_t row0, int64_t n_rows) {
     v.x = (row0 + 0 < n_rows && v.x == v.x) ? v.x : -INFINITY;

@@ -74,25 +74,21 @@ def test_other_dimensions(dim):
 
 @pytest.mark.parametrize("batch", [1, 2, 3, 4, 5, 8, 9, 16, 17, 32, 33, 64, 65, 130])
 def test_batches_and_batch_invariance(batch):
-    V = synth.unit_rows(30000, 384, 11)
+    V = synth.unit_rows(100_000, 384, 11)        # (>= 8 x pool tiles: below that every batch runs the VALU scans)
     Q = synth.unit_rows(batch, 384, 12)
     ix = ProductIndex(V)
     rows, scores = check_against_oracle(V, Q, 150, ix)
-    # Batches of <= 4 run the per-row-chain kernel: a query's answer is bitwise the same in any
-    # such batch.  Larger batches run a matrix-core kernel (16x16x32 tiles for 5..16 queries,
-    # 32x32x16 tiles for 17..64), whose (equally fixed) summation orders differ: across kernels the
-    # answers agree to f32 rounding, and each is checked against the oracle.
+    # Batches of <= 4 run the per-row-chain VALU scan; larger ones the bf16 filter scan whose candidates
+    # are rescored with that same per-row chain: a query's answer is bitwise the same alone and in
+    # any batch (queries are taken 128 at a time).
     r1, s1 = ix.dense_topk(Q[-1:], 150)
-    tail = batch % 64 or 64                # queries are taken 64 at a time; the last query sits in the tail chunk
-    if tail <= 4:
-        assert np.array_equal(r1[0], rows[-1]) and np.array_equal(s1[0], scores[-1])
-    else:
-        np.testing.assert_allclose(s1[0], scores[-1], atol=2e-7, rtol=0)
-        # each matrix-core kernel is itself batch-invariant: same query in another batch of its class
-        extra = 4 + (batch % 7) if tail <= 16 else 20 + (batch % 7)
-        Q2 = np.concatenate([synth.unit_rows(extra, 384, 13), Q[-1:]])
+    assert np.array_equal(r1[0], rows[-1]) and np.array_equal(s1[0].view(np.uint32), scores[-1].view(np.uint32))
+    if batch > 4:
+        assert ix.select_trace()[0] in (1, 2)
+        Q2 = np.concatenate([synth.unit_rows(4 + (batch % 7), 384, 13), Q[-1:]])
         r2, s2 = ix.dense_topk(Q2, 150)
-        assert np.array_equal(r2[-1], rows[-1]) and np.array_equal(s2[-1], scores[-1])
+        assert ix.select_trace()[0] == 2, "the filter + rescoring path must be the one that ran"
+        assert np.array_equal(r2[-1], rows[-1]) and np.array_equal(s2[-1].view(np.uint32), scores[-1].view(np.uint32))
     ix.close()
 
 
@@ -107,31 +103,49 @@ def test_matrix_core_scan_ragged_tail_and_ties():
         check_against_oracle(V, Q, min(150, n))
 
 
+def _same_up_to_rounding(rows_a, sc_a, rows_b, sc_b, atol=5e-7):
+    """Two exact-arithmetic variants of one search: scores agree to fp32 rounding; rows may swap only
+    where neighbouring scores are that close."""
+    np.testing.assert_allclose(sc_a, sc_b, atol=atol, rtol=0)     # (a 24-element fmaf chain x 16 partials vs split bf16 terms)
+    diff = rows_a != rows_b
+    if diff.any():
+        gaps = np.abs(np.diff(sc_a.astype(np.float64), axis=-1))
+        near = np.zeros_like(diff)
+        near[..., :-1] |= gaps < 2 * atol
+        near[..., 1:] |= gaps < 2 * atol
+        assert not (diff & ~near).any(), "rows differ where the scores are well separated"
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("batch", [9, 16, 17, 40, 64])
-def test_two_pass_batched_scan_equals_the_stored_score_pass(batch, dtype):
-    # default: the scan keeps only M-tile maxima and the candidate M-tiles are rescored
-    # (trace[0] == 2); diagnostic mode: the single pass that stores every score.  Bit-equal.
+@pytest.mark.parametrize("batch", [5, 16, 17, 40, 64, 100, 128, 130])
+def test_filter_scan_plus_rescoring_is_bitwise_the_single_query_scan(batch, dtype):
+    # default batched path: bf16 filter scan -> candidate M-tiles -> per-row-chain rescoring (trace[0] == 2).
+    # Its answer must be the single-query scan's, bit for bit; the stored-score pass of the split-operand
+    # scan (diagnostic mode, also the per-query fallback) agrees to fp32 rounding.
     V = synth.unit_rows(300_000, 384, 77)
     V[1000:1040] = V[11]                         # ties across M-tiles
     Q = synth.unit_rows(batch, 384, 78)
     Q[3] = V[11]
     ix = ProductIndex(V) if dtype == "f32" else ProductIndex.from_rows(V, dtype="bf16")
     rows2, sc2 = ix.dense_topk(Q, 150)
-    assert ix.select_trace()[0] == 2, "the two-pass path must be the one that ran"
+    tail = batch % 128 or 128                    # queries are taken 128 at a time; a tail of <= 4 runs the VALU scan
+    assert ix.select_trace()[0] == (2 if tail > 4 else 1), "the filter + rescoring path must be the one that ran"
+    for i in (0, 3, batch - 1):
+        r1, s1 = ix.dense_topk(Q[i:i + 1], 150)
+        assert np.array_equal(r1[0], rows2[i]) and np.array_equal(s1[0].view(np.uint32), sc2[i].view(np.uint32))
     ix.set_scan_mode(stored=True)
-    rows1, sc1 = ix.dense_topk(Q, 150)
+    rows1, sc1 = ix.dense_topk(Q[:64], 150)
     assert ix.select_trace()[0] == 1
     ix.set_scan_mode(stored=False)
-    assert np.array_equal(rows1, rows2) and np.array_equal(sc1.view(np.uint32), sc2.view(np.uint32))
+    _same_up_to_rounding(rows1, sc1, rows2[:64], sc2[:64])
     if dtype == "f32":
-        check_against_oracle(V, Q[:6], 150, index=ix)     # (VALU path for <= 4; 6 -> matrix cores)
+        check_against_oracle(V, Q[:6], 150, index=ix)
     ix.close()
 
 
-def test_two_pass_falls_back_per_query_on_massive_ties():
-    # query 0 ties on > 2048 M-tiles (its candidate list overflows -> flagged, stored-score fallback);
-    # the other queries of the batch stay on the two-pass path.  Both kinds must be exact.
+def test_filter_path_falls_back_per_query_on_massive_ties():
+    # query 0 ties on > 2048 M-tiles (its candidate list overflows -> flagged -> stored-score pass);
+    # the other queries of the batch stay on the filter path.  Both kinds must be exact.
     V = synth.unit_rows(200_000, 384, 91)
     V[::50] = V[3]                               # 4000 copies of row 3, spread over 4000 M-tiles
     Q = synth.unit_rows(20, 384, 92)
@@ -140,11 +154,63 @@ def test_two_pass_falls_back_per_query_on_massive_ties():
     rows, scores = ix.dense_topk(Q, 150)
     assert rows[0].tolist() == sorted({3} | set(range(0, 50 * 150, 50)))[:150]   # equal scores -> ascending row
     assert np.all(scores[0] == scores[0][0])
+    r1, s1 = ix.dense_topk(Q[5:6], 150)          # a query that stayed on the filter path
+    assert np.array_equal(r1[0], rows[5]) and np.array_equal(s1[0], scores[5])
     ix.set_scan_mode(stored=True)
     rows1, sc1 = ix.dense_topk(Q, 150)
     ix.set_scan_mode(stored=False)
-    assert np.array_equal(rows1, rows) and np.array_equal(sc1.view(np.uint32), scores.view(np.uint32))
+    _same_up_to_rounding(rows1, sc1, rows, scores)
     check_against_oracle(V, Q[:8], 150, index=ix)
+    ix.close()
+
+
+def test_filter_path_rows_and_queries_of_any_norm():
+    # the filter's error bound scales with the largest row norm and the query norm: rows from 0.01 to 30
+    # long (one bound for all of them: loose for the short rows, more candidates, same answer)
+    V = synth.unit_rows(120_000, 384, 301)
+    V *= np.geomspace(0.01, 30.0, len(V), dtype=np.float32)[np.random.default_rng(5).permutation(len(V))][:, None]
+    Q = synth.unit_rows(24, 384, 302) * np.float32(7.5)
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(Q, 150)
+    for i in range(len(Q)):
+        ref64 = OD.sims_float64(V, Q[i])
+        assert_topk_matches(rows[i], scores[i], ref64, 150, tie_eps=4e-7 * 225, score_tol=1e-5 * 225)
+        r1, s1 = ix.dense_topk(Q[i:i + 1], 150)
+        assert np.array_equal(r1[0], rows[i]) and np.array_equal(s1[0].view(np.uint32), scores[i].view(np.uint32))
+    ix.close()
+
+
+def test_filter_path_crowded_cut_still_exact():
+    # 6000 rows within ~1e-5 of each other around the cut: bf16 scores cannot tell them apart, the
+    # candidate lists overflow for that query and the exact pass serves it; the rest stay filtered
+    rng = np.random.default_rng(11)
+    V = synth.unit_rows(150_000, 384, 401)
+    u = synth.unit_rows(1, 384, 402)[0]
+    crowd = u[None, :] + 3e-3 * rng.standard_normal((6000, 384)).astype(np.float32)
+    V[rng.choice(len(V), 6000, replace=False)] = crowd / np.linalg.norm(crowd, axis=1, keepdims=True)
+    Q = synth.unit_rows(12, 384, 403)
+    Q[0] = u
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(Q, 150)
+    for i in range(len(Q)):
+        # (fp32 itself reorders this crowd against float64: a wider tie band than elsewhere)
+        assert_topk_matches(rows[i], scores[i], OD.sims_float64(V, Q[i]), 150, tie_eps=2e-6)
+        r1, s1 = ix.dense_topk(Q[i:i + 1], 150)
+        _same_up_to_rounding(r1, s1, rows[i:i + 1], scores[i:i + 1], atol=2e-6)   # (scores near 1: same-sign chains)
+    ix.close()
+
+
+def test_batched_search_with_a_nan_row_takes_the_exact_scans():
+    V = synth.unit_rows(20_000, 384, 41)
+    V[5, 3] = np.nan                             # no finite row-norm bound: no filtering
+    Q = synth.unit_rows(20, 384, 42)
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(Q, 150)
+    assert 5 not in rows.ravel().tolist() and np.isfinite(scores).all()
+    Vc = V.copy(); Vc[5] = 0
+    for i in (0, 19):
+        ref64 = OD.sims_float64(Vc, Q[i]); ref64[5] = -np.inf
+        assert_topk_matches(rows[i], scores[i], ref64, 150)
     ix.close()
 
 

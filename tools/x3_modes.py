@@ -15,7 +15,7 @@ if dtype == "bf16":
     mat = mat.to(torch.bfloat16)
 ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=mat.data_ptr(), keepalive=mat, dtype=dtype)
 pool = 150
-for b in (16, 32, 64):
+for b in (16, 32, 64, 128):
     q = torch.randn((b, 384), device="cuda")
     rows = torch.empty((b, pool), dtype=torch.int64, device="cuda"); sc = torch.empty((b, pool), device="cuda")
     def call():
