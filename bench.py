@@ -298,9 +298,10 @@ def main():
         # WRITE_SIZE, MI355X_MICROARCH.md), measured on this kernel at this many queries per launch
         # on 10M rows; the same bytes-per-row ratio is applied to this run's rows.  null when no
         # PMC summary for this launch shape is present.
-        qpl = min(args.batch, 64) if args.batch > 4 else args.batch   # queries sharing one matrix read
+        exact = bool(os.environ.get("RR_SCAN_EXACT"))
+        qpl = min(args.batch, 64 if exact else 128) if args.batch > 4 else args.batch   # queries sharing one matrix read
         traffic = None
-        chain_tag = "chain_" if (os.environ.get("RR_SCAN_F32_CHAIN") and qpl > 4) else ""
+        chain_tag = ("chain_" if os.environ.get("RR_SCAN_F32_CHAIN") else "exact_" if exact else "") if qpl > 4 else ""
         pmc = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_scan_{chain_tag}b{qpl}_10M.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
@@ -313,16 +314,17 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         chain = bool(os.environ.get("RR_SCAN_F32_CHAIN"))
         if qpl > 4 and not chain:
-            # 5..64 queries per read run on the bf16 matrix cores with exactly-split operands
-            # (rr_dense_x3.hip up to 16 queries, rr_dense_x3w.hip beyond): 6 (fp32 storage) or 3 (bf16
-            # storage) MFMA terms per dim.  Both the HBM
+            # 5..128 queries per read: bf16 filter scan on the matrix cores (rr_dense_flt.hip: one MFMA term per
+            # dim, candidates rescored exactly) -- or, with RR_SCAN_EXACT=1, the split-operand scans (6 terms for
+            # fp32 storage, 3 for bf16; rr_dense_x3.hip up to 16 queries, rr_dense_x3w.hip up to 64).  Both the HBM
             # fraction and the matrix-core fraction are reported; the larger one names the bound.
-            terms = 3 if args.dtype == "bf16" else 6
+            terms = 1 if not exact else (3 if args.dtype == "bf16" else 6)
             pf = terms * 2.0 * n_local * DIM * qpl / (avg_ms * 1e-3) / 1e15 if launches else 0.0
             hbm_frac, mfma_frac = achieved / HBM_PEAK_GBS, pf / 2.5
             roof = {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic,
-                    "kernel": (f"rr_scan_mfma_x3<1,{args.dtype}>" if qpl <= 16 else
+                    "kernel": (f"rr_scan_flt<{1 if qpl <= 32 else 2 if qpl <= 64 else 4},{args.dtype}>" if not exact else
+                               f"rr_scan_mfma_x3<1,{args.dtype}>" if qpl <= 16 else
                                f"rr_scan_x3w<{1 if qpl <= 32 else 2},{args.dtype}>"),
                     "matrix_core_pflops": round(pf, 4), "matrix_core_frac_of_2.5PF": round(mfma_frac, 4)}
             if mfma_frac > hbm_frac:
