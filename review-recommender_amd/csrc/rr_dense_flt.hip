@@ -167,14 +167,11 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
 
     int qlane = c * RR_FLT_QSTRIDE + h;               // 16-byte unit index into qs: + 32 t * QSTRIDE + 2 * kk
     float gm[NQ2];                                    // running maximum of the current group (sub-run of tiles)
-    float2 pend[NQ2];                                 // maxima of the M-tile just finished, stored one M-tile late,
-    uint32_t pend_key[NQ2];                           // ... with the group's running maximum (the last store wins)
-    int64_t pend_group = wave * G.gpw;
+    float2 pend[NQ2];                                 // maxima of the M-tile just finished, stored one M-tile late
 #pragma unroll
     for (int t = 0; t < NQ2; ++t) {
         gm[t] = -INFINITY;
         pend[t] = float2{-INFINITY, -INFINITY};
-        pend_key[t] = 0u;
     }
     auto read_q = [&](int t, int kk) { return __builtin_bit_cast(bf16x8, qs[qlane + 32 * t * RR_FLT_QSTRIDE + 2 * kk]); };
     // fp32 pair (lo, hi = dims 8h .. 8h+7 of the K-step) -> one bf16x8 operand, round to nearest even
@@ -190,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
     constexpr int VPS = (NV + NQ2 - 1) / NQ2;
     u32x4 lo, hi, nxt;             // the pair being prepared (MFMA lanes) and its bf16 operand
     bf16x8 af;                     // operand of the current K-step
-    bf16x8 qf[2][NQ2];             // B fragments, two K-steps
+    bf16x8 qf[2][NQ2];             // B fragments of this K-step and the next (each re-loaded in place for two steps on)
     auto valu_op = [&](int k, const u32x4& x, const u32x4& y) {
         if (k < 4) {
             const auto r = __builtin_amdgcn_permlane16_swap(x[k], y[k], false, false);
@@ -205,7 +202,10 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
         for (int k = 0; k < 8; ++k) valu_op(k, a[0], a[1]);
         af = __builtin_bit_cast(bf16x8, A_BF16 ? lo : nxt);
 #pragma unroll
-        for (int t = 0; t < NQ2; ++t) qf[0][t] = read_q(t, 0);
+        for (int t = 0; t < NQ2; ++t) {
+            qf[0][t] = read_q(t, 0);
+            qf[1][t] = read_q(t, 1);
+        }
     }
 
 #pragma unroll 1
@@ -222,13 +222,14 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
             for (int s = 0; s < STEPS; ++s) {
                 const int cb = (p * STEPS + s) & 1;
                 const int s2 = (s + 1) % STEPS;                           // the K-step being prepared
-                const int kk2 = A_BF16 ? s2 : (12 * p + s + 1) % 24;      // ... as K-step of the row
+                constexpr int LEAD = NQ2 >= 4 ? 1 : 2;                    // K-steps of B-fragment prefetch (4 tiles: no registers for 2)
+                const int kk3 = A_BF16 ? (s + LEAD) % 24 : (12 * p + s + LEAD) % 24;   // K-step of the row LEAD steps ahead
                 const bool swap = A_BF16 ? (s2 % 2 == 0) : true;          // it starts a new pair of the ring
                 const int np = A_BF16 ? s2 / 2 : s2;
                 constexpr int REFILL_SLOT = 3 / VPS;                      // the slot that issues the last lane swap
                 if (swap && (np == 6 || np == 0)) {
                     // ring waits and deferred maxima stores exactly as in rr_scan_x3w
-                    if (p == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + 2 * NQ2) : "memory");
+                    if (p == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + NQ2) : "memory");
                     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
                     for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(a[(np / 6) * 12 + j]));
@@ -240,7 +241,10 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
 #pragma unroll
                         for (int k = VPS * j; k < VPS * j + VPS; ++k) valu_op(k, a[2 * np], a[2 * np + 1]);
                     }
-                    qf[cb ^ 1][j] = read_q(j, kk2);
+                    // B fragment of the K-step after next, into the register the MFMA above just consumed: two
+                    // K-steps (2 NQ2 MFMA slots) of lead instead of one (s_waitcnt lgkmcnt sat in front of every MFMA)
+                    if (LEAD == 2) qf[cb][j] = read_q(j, kk3);
+                    else qf[cb ^ 1][j] = read_q(j, kk3);
                     if (swap && (np == 5 || np == 11) && j == REFILL_SLOT) {
                         // the lane swaps of this half's last pair are issued: re-load the half
 #pragma unroll
@@ -248,16 +252,13 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
 #pragma unroll
                         for (int u = 1; u < 12; u += 2) RR_FLT_LOAD(a[(np / 6) * 12 + u], (np / 6) * 12 + u);
                         if (p == 0 && np == 5) {
-                            // 2 NQ2 stores, always (the ring waits count them): the previous M-tile's maxima and
-                            // its group's running maximum.  First M-tile of the wave: nothing pending -- the
-                            // stores go to its own slots, overwritten by this wave one M-tile later.
+                            // NQ2 stores, always (the ring waits count them): the previous M-tile's maxima.  First
+                            // M-tile of the wave: nothing pending -- the stores go to its own slot, overwritten by
+                            // this wave one M-tile later.
                             const int64_t mprev = mt > m0 ? mt - 1 : mt;
 #pragma unroll
                             for (int t = 0; t < NQ2; ++t)
-                                if (h == 0) {
-                                    *reinterpret_cast<float2*>(gmax + ((mprev * QN + 32 * t + c) << 1)) = pend[t];
-                                    smax[pend_group * QN + 32 * t + c] = pend_key[t];
-                                }
+                                if (h == 0) *reinterpret_cast<float2*>(gmax + ((mprev * QN + 32 * t + c) << 1)) = pend[t];
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -284,14 +285,17 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
             m16[1] = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
             gm[t] = fmaxf(gm[t], fmaxf(m16[0], m16[1]));
             pend[t] = float2{m16[0], m16[1]};
-            pend_key[t] = rr_f2key(gm[t]);
         }
-        {   // group k of the wave = tiles [t0 + k Cg, t0 + (k + 1) Cg) of its run
+        {   // group k of the wave = tiles [t0 + k Cg, t0 + (k + 1) Cg) of its run.  Its maximum is stored at once:
+            // the next ring wait then covers a fresh store and stalls (~2 us), once per ~19 tiles.
             const int in_run = (int)((mt >> 1) - t0), cg = (int)G.tiles_per_group;
-            pend_group = wave * G.gpw + in_run / cg;
-            if ((mt & 1) == 1 && (in_run + 1) % cg == 0) {
+            if ((mt & 1) == 1 && ((in_run + 1) % cg == 0 || mt == m1 - 1)) {
+                const int64_t group = wave * G.gpw + in_run / cg;
 #pragma unroll
-                for (int t = 0; t < NQ2; ++t) gm[t] = -INFINITY;
+                for (int t = 0; t < NQ2; ++t) {
+                    if (h == 0) smax[group * QN + 32 * t + c] = rr_f2key(gm[t]);
+                    gm[t] = -INFINITY;
+                }
             }
         }
     }
@@ -300,7 +304,6 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
             *reinterpret_cast<float2*>(gmax + (((m1 - 1) * QN + 32 * t + c) << 1)) = pend[t];
-            smax[pend_group * QN + 32 * t + c] = pend_key[t];
         }
     }
 }
