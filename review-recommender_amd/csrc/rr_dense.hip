@@ -32,7 +32,7 @@
 #define RR_SEL_THREADS 1024
 #define RR_SEL_GCAP 4096    // slow path: tiles kept in LDS
 #define RR_SEL_CCAP 8192    // candidate rows kept in LDS
-#define RR_SEL_LCAP 1024    // groups opened by the fast path
+#define RR_SEL_LCAP 4096    // groups opened by the fast path
 
 // ------------------------------------------------------------------ scan
 template <int NF>
