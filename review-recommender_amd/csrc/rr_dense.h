@@ -20,7 +20,9 @@ struct rr_scan_geom {
                               //    one contiguous block of whole 128-B lines)
     int64_t n_pad;            // 64 * n_tiles
     int32_t mm_pairs;         // M-tile maxima of the two-pass path: 0 = [tile][Q][4] (rr_scan_mfma_x3),
-                              // 1 = [32-row tile][Q][2] (rr_scan_x3w: whole lines per store)
+                              // 1 = [32-row tile][Q][2] (rr_scan_x3w: whole lines per store),
+                              // 2 = [32-row tile][Q][4 x bf16, rounded up] of 8-ROW M-tiles (rr_scan_flt): the listed ids
+                              //     and the rescoring scratch are then per 8 rows
     int32_t gpw;              // groups per wave (0 or 1: the wave's whole run is one group); rr_scan_flt cuts a run into
     int64_t tiles_per_group;  //   gpw sub-runs of tiles_per_group tiles, group g = wave * gpw + k: fewer tiles to open per group
 };

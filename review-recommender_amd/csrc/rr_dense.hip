@@ -805,7 +805,22 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
             const int64_t t = (int64_t)(g / gpw) * G.tiles_per_wave + in_run;
             if (in_run >= G.tiles_per_wave || t >= G.n_tiles) continue;
             float v[4];
-            if (G.mm_pairs) {
+            if (G.mm_pairs == 2) {          // 8-row M-tiles: two 32-row tiles x four bf16 maxima each
+                const uint2 w0 = reinterpret_cast<const uint2*>(mmax)[(2 * t) * QS + q];
+                const uint2 w1 = reinterpret_cast<const uint2*>(mmax)[(2 * t + 1) * QS + q];
+                const float u[8] = {__uint_as_float(w0.x << 16), __uint_as_float(w0.x & 0xFFFF0000u),
+                                    __uint_as_float(w0.y << 16), __uint_as_float(w0.y & 0xFFFF0000u),
+                                    __uint_as_float(w1.x << 16), __uint_as_float(w1.x & 0xFFFF0000u),
+                                    __uint_as_float(w1.y << 16), __uint_as_float(w1.y & 0xFFFF0000u)};
+#pragma unroll
+                for (int sub = 0; sub < 8; ++sub) {
+                    if (rr_f2key(u[sub]) >= open) {
+                        const uint32_t slot = atomicAdd(&counters[1], 1u);
+                        if (slot < RR_X3_MCAP) out_mtiles[(int64_t)q * RR_X3_MCAP + slot] = (uint32_t)(t * 8 + sub);
+                    }
+                }
+                continue;
+            } else if (G.mm_pairs) {
                 const float2 m0 = reinterpret_cast<const float2*>(mmax)[(2 * t) * QS + q];
                 const float2 m1 = reinterpret_cast<const float2*>(mmax)[(2 * t + 1) * QS + q];
                 v[0] = m0.x, v[1] = m0.y, v[2] = m1.x, v[3] = m1.y;
@@ -849,12 +864,14 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
     if (tid < 2) counters[tid] = 0;
     __syncthreads();
     const uint32_t tau = tau_of[q];
-    const int n1 = count[q] * 16;
+    const int sh = G.mm_pairs == 2 ? 3 : 4;           // rows per listed M-tile: 8 or 16
+    const int n1 = count[q] << sh;
     for (int i = tid; i < n1; i += RR_SEL_THREADS) {
-        const int64_t at = (int64_t)q * RR_X3_MCAP + (i >> 4);
-        const uint32_t row = mtiles[at] * 16u + (uint32_t)(i & 15);
+        const int64_t at = (int64_t)q * RR_X3_MCAP + (i >> sh);
+        const int r = i & ((1 << sh) - 1);
+        const uint32_t row = (mtiles[at] << sh) + (uint32_t)r;
         if ((int64_t)row < G.n_rows) {
-            const uint32_t key = rr_f2key(sc[at * 16 + (i & 15)]);
+            const uint32_t key = rr_f2key(sc[(at << sh) + r]);
             if (key >= tau) {
                 const uint32_t slot = atomicAdd(&counters[0], 1u);
                 if (slot < RR_SEL_CCAP / 2) cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - row);

@@ -167,11 +167,11 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
 
     int qlane = c * RR_FLT_QSTRIDE + h;               // 16-byte unit index into qs: + 32 t * QSTRIDE + 2 * kk
     float gm[NQ2];                                    // running maximum of the current group (sub-run of tiles)
-    float2 pend[NQ2];                                 // maxima of the M-tile just finished, stored one M-tile late
+    uint2 pend[NQ2];                                  // 8-row maxima of the 32-row tile just finished (4 x bf16), stored one tile late
 #pragma unroll
     for (int t = 0; t < NQ2; ++t) {
         gm[t] = -INFINITY;
-        pend[t] = float2{-INFINITY, -INFINITY};
+        pend[t] = uint2{0xFF80FF80u, 0xFF80FF80u};    // -inf
     }
     auto read_q = [&](int t, int kk) { return __builtin_bit_cast(bf16x8, qs[qlane + 32 * t * RR_FLT_QSTRIDE + 2 * kk]); };
     // fp32 pair (lo, hi = dims 8h .. 8h+7 of the K-step) -> one bf16x8 operand, round to nearest even
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
                             const int64_t mprev = mt > m0 ? mt - 1 : mt;
 #pragma unroll
                             for (int t = 0; t < NQ2; ++t)
-                                if (h == 0) *reinterpret_cast<float2*>(gmax + ((mprev * QN + 32 * t + c) << 1)) = pend[t];
+                                if (h == 0) *reinterpret_cast<uint2*>(gmax + ((mprev * QN + 32 * t + c) << 1)) = pend[t];
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -272,19 +272,31 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
         const bool full = mt * 32 + 32 <= G.n_rows;
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
-            float m16[2] = {-INFINITY, -INFINITY};
+            // maxima of the four 8-row M-tiles (rows 8g .. 8g + 7 = registers 4g .. 4g + 3 of both k halves)
+            float m8[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
                 if (!full) v = rr_x3_canon(v, rbase + 8 * g, G.n_rows);            // (fmaxf drops a NaN by itself)
-                m16[g >> 1] = fmaxf(m16[g >> 1], fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+                m8[g] = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
             }
-            const auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m16[0]), __float_as_uint(m16[0]), false, false);
-            const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m16[1]), __float_as_uint(m16[1]), false, false);
-            m16[0] = fmaxf(__uint_as_float(r0[0]), __uint_as_float(r0[1]));
-            m16[1] = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
-            gm[t] = fmaxf(gm[t], fmaxf(m16[0], m16[1]));
-            pend[t] = float2{m16[0], m16[1]};
+            uint32_t pk[2];
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                // the other k half's rows (lane l ^ 32), then both maxima as bf16 ROUNDED UP: the filter only asks
+                // "can this M-tile hold a score >= threshold", so an upper bound in 16 bits is all it needs
+                float a0 = m8[2 * g2], a1 = m8[2 * g2 + 1];
+                const auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a0), false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1), __float_as_uint(a1), false, false);
+                a0 = fmaxf(__uint_as_float(r0[0]), __uint_as_float(r0[1]));
+                a1 = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
+                gm[t] = fmaxf(gm[t], fmaxf(a0, a1));
+                const uint32_t b0 = __float_as_uint(a0), b1 = __float_as_uint(a1);
+                const uint32_t u0 = (b0 >> 31) ? (b0 >> 16) : ((b0 + 0xFFFFu) >> 16);     // toward +inf; +-inf stay
+                const uint32_t u1 = (b1 >> 31) ? (b1 >> 16) : ((b1 + 0xFFFFu) >> 16);
+                pk[g2] = u0 | (u1 << 16);
+            }
+            pend[t] = uint2{pk[0], pk[1]};
         }
         {   // group k of the wave = tiles [t0 + k Cg, t0 + (k + 1) Cg) of its run.  Its maximum is stored at once:
             // the next ring wait then covers a fresh store and stalls (~2 us), once per ~19 tiles.
@@ -303,15 +315,15 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
     if (h == 0) {
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
-            *reinterpret_cast<float2*>(gmax + (((m1 - 1) * QN + 32 * t + c) << 1)) = pend[t];
+            *reinterpret_cast<uint2*>(gmax + (((m1 - 1) * QN + 32 * t + c) << 1)) = pend[t];
         }
     }
 }
 
 // ------------------------------------------------------------------ exact rescoring
-// One wave per (query, listed 16-row M-tile): the single-query scans' per-row arithmetic -- lane j of
+// One wave per (query, listed 8-row M-tile): the single-query scans' per-row arithmetic -- lane j of
 // a 16-lane row takes 16-byte units j, j + 16, ... of the row, one fmaf chain over its 24 elements in
-// ascending order, rr_row16_sum over the row (rr_scan_f32<6,1> / rr_scan_bf16<1>).  sc[query][slot][16].
+// ascending order, rr_row16_sum over the row (rr_scan_f32<6,1> / rr_scan_bf16<1>).  sc[query][slot][8].
 template <bool A_BF16>
 __global__ __launch_bounds__(256) void rr_rescore_chain(
     const void* __restrict__ mat, int64_t n_rows, const float* __restrict__ queries,   // [nq][384] fp32, padded
@@ -335,11 +347,11 @@ __global__ __launch_bounds__(256) void rr_rescore_chain(
         for (int i = 0; i < 6; ++i) qreg[i] = qv[16 * i + sub];
     }
     for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n; slot += gridDim.x * 4) {
-        const int64_t m16 = mtiles[(int64_t)q * RR_X3_MCAP + slot];
+        const int64_t m8 = mtiles[(int64_t)q * RR_X3_MCAP + slot];
         float mine = 0.f;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {                   // four rows per step: lane (sub, grp) -> row 4 it + grp
-            int64_t row = m16 * 16 + 4 * it + grp;
+        for (int it = 0; it < 2; ++it) {                   // four rows per step: lane (sub, grp) -> row 4 it + grp
+            int64_t row = m8 * 8 + 4 * it + grp;
             row = row < n_rows ? row : n_rows - 1;
             float acc = 0.f;
             if (A_BF16) {
@@ -369,13 +381,13 @@ __global__ __launch_bounds__(256) void rr_rescore_chain(
                 }
             }
             acc = rr_row16_sum(acc);
-            mine = (sub == it) ? acc : mine;               // lane (sub, grp) keeps row 4 sub + grp (sub < 4)
+            mine = (sub == it) ? acc : mine;               // lane (sub, grp) keeps row 4 sub + grp (sub < 2)
         }
-        if (sub < 4) {
+        if (sub < 2) {
             const int r = 4 * sub + grp;
-            const int64_t row = m16 * 16 + r;
+            const int64_t row = m8 * 8 + r;
             const float v = (row < n_rows && mine == mine) ? mine : -INFINITY;   // NaN scores and pad rows rank last
-            sc[((int64_t)q * RR_X3_MCAP + slot) * 16 + r] = v;
+            sc[((int64_t)q * RR_X3_MCAP + slot) * 8 + r] = v;
         }
     }
 }
@@ -412,7 +424,7 @@ static int rr_dense_chunk_flt_t(rr_index* ix, const float* d_q, int nq, int pool
     if (!waves) waves = rr_resident_waves((const void*)rr_scan_flt<NQ2, A_BF16>, THREADS, ix->device);
     rr_scan_geom G = rr_make_geom(ix, waves / 4);
     G.qs = QN;
-    G.mm_pairs = 1;
+    G.mm_pairs = 2;
     // selection groups = quarter runs: ~4x fewer tile maxima to open per group (at most 8192 groups)
     G.gpw = RR_MAX_SCAN_WAVES / G.n_waves < 4 ? (RR_MAX_SCAN_WAVES / G.n_waves < 1 ? 1 : RR_MAX_SCAN_WAVES / G.n_waves) : 4;
     if (G.gpw > G.tiles_per_wave) G.gpw = (int32_t)G.tiles_per_wave;
