@@ -120,11 +120,18 @@ __global__ __launch_bounds__(256) void rr_row_norm_max(const void* __restrict__ 
 }
 
 // ------------------------------------------------------------------ the filter scan
+// RR_FLT_THREADS(NQ2): workgroup size.  Four query tiles want 270 registers for a B-fragment lead of two
+// K-steps; RR_FLT_ONE_WAVE=1 builds that variant (one wave per SIMD, the whole register file, lead 2):
+// measured equal to two waves per SIMD with lead 1 (scan(128 q) / scan(32 q) = 1.14 either way), so off.
+#define RR_FLT_THREADS(NQ2) ((NQ2) >= 4 && RR_FLT_ONE_WAVE ? 256 : 512)
+#ifndef RR_FLT_ONE_WAVE
+#define RR_FLT_ONE_WAVE 0
+#endif
 template <int NQ2, bool A_BF16>
-__global__ __launch_bounds__(512, 2) void rr_scan_flt(
+__global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 1 : 2)) void rr_scan_flt(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [32*NQ2][48] units
     float* __restrict__ gmax, uint32_t* __restrict__ smax) {
-    constexpr int THREADS = 512;
+    constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
     constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
     constexpr int SEGS = A_BF16 ? 1 : 2;              // ring segments (24 units per lane) per 32-row M-tile
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt(
             for (int s = 0; s < STEPS; ++s) {
                 const int cb = (p * STEPS + s) & 1;
                 const int s2 = (s + 1) % STEPS;                           // the K-step being prepared
-                constexpr int LEAD = NQ2 >= 4 ? 1 : 2;                    // K-steps of B-fragment prefetch (4 tiles: no registers for 2)
+                constexpr int LEAD = (NQ2 >= 4 && THREADS == 512) ? 1 : 2;   // K-steps of B-fragment prefetch (4 tiles x 2 waves/SIMD: no registers for 2)
                 const int kk3 = A_BF16 ? (s + LEAD) % 24 : (12 * p + s + LEAD) % 24;   // K-step of the row LEAD steps ahead
                 const bool swap = A_BF16 ? (s2 % 2 == 0) : true;          // it starts a new pair of the ring
                 const int np = A_BF16 ? s2 / 2 : s2;
@@ -418,7 +425,7 @@ static int rr_flt_get_bounds(rr_index* ix, hipStream_t st, rr_flt_bounds* out) {
 template <int NQ2, bool A_BF16>
 static int rr_dense_chunk_flt_t(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                                 float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
-    constexpr int THREADS = 512;
+    constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
     static int waves = 0;
     if (!waves) waves = rr_resident_waves((const void*)rr_scan_flt<NQ2, A_BF16>, THREADS, ix->device);
