@@ -38,7 +38,7 @@ void rr_scan_events_end(rr_index* ix, int slot, hipStream_t st);
 void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                       float* d_scores, hipStream_t st, const int32_t* only_if = nullptr);
 // Two-pass selection of the split-operand scan (see rr_select_mtiles in rr_dense.hip).
-#define RR_X3_MCAP 8192          // M-tiles (16 rows) one query may ask to have rescored
+#define RR_X3_MCAP 16384         // M-tiles (8 or 16 rows) one query may ask to have rescored
 struct rr_x3_scratch {           // (every array RR_FLT_MAXQ queries long)
     uint32_t* mtiles;            // [q][RR_X3_MCAP] M-tile ids to rescore
     int32_t* count;              // [q] how many

@@ -31,7 +31,8 @@
 
 #define RR_SEL_THREADS 1024
 #define RR_SEL_GCAP 4096    // slow path: tiles kept in LDS
-#define RR_SEL_CCAP 8192    // candidate rows kept in LDS
+#define RR_SEL_CCAP 12288   // candidate keys in LDS: the fast paths collect into the first half (6144) and sort in <= 8192
+#define RR_SEL_SORTCAP 8192 // largest power of two inside it: the generic path collects up to this many
 #define RR_SEL_LCAP 4096    // groups opened by the fast path
 
 // ------------------------------------------------------------------ scan
@@ -431,7 +432,7 @@ __device__ void rr_select_slow(ScoreAt score_at, TileMaxAt tile_max_at,
             const uint32_t key = rr_f2key(score_at(row));
             if (key >= tau_key) {
                 const uint32_t slot = atomicAdd(&counters[1], 1u);
-                if (slot < RR_SEL_CCAP)
+                if (slot < RR_SEL_SORTCAP)
                     cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)row);
             }
         }
@@ -439,7 +440,7 @@ __device__ void rr_select_slow(ScoreAt score_at, TileMaxAt tile_max_at,
     __syncthreads();
     uint32_t n_cand = counters[1];
 
-    if (n_cand > RR_SEL_CCAP) {
+    if (n_cand > RR_SEL_SORTCAP) {
         // ---- 3b. too many survivors: exact radix select of the pool-th largest
         // 64-bit key over the same rows, then keep keys >= it (exactly pool of them).
         uint64_t prefix = 0, mask = 0;
@@ -473,16 +474,16 @@ __device__ void rr_select_slow(ScoreAt score_at, TileMaxAt tile_max_at,
                                      (uint64_t)(0xFFFFFFFFu - (uint32_t)row);
                 if (key >= prefix) {
                     const uint32_t slot = atomicAdd(&counters[1], 1u);
-                    if (slot < RR_SEL_CCAP) cand[slot] = key;
+                    if (slot < RR_SEL_SORTCAP) cand[slot] = key;
                 }
             }
         }
         __syncthreads();
-        n_cand = counters[1] < RR_SEL_CCAP ? counters[1] : RR_SEL_CCAP;  // == pool
+        n_cand = counters[1] < RR_SEL_SORTCAP ? counters[1] : RR_SEL_SORTCAP;  // == pool
     }
 
     // ---- 4. order the survivors (score desc, row asc) and emit the first pool
-    if (n_cand > RR_SEL_CCAP) n_cand = RR_SEL_CCAP;   // cannot happen for consistent inputs; never overrun LDS
+    if (n_cand > RR_SEL_SORTCAP) n_cand = RR_SEL_SORTCAP;   // cannot happen for consistent inputs; never overrun LDS
     int n_sort = 1;
     while (n_sort < (int)n_cand) n_sort <<= 1;
     for (int i = tid; i < n_sort; i += RR_SEL_THREADS)

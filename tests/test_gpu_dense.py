@@ -144,15 +144,15 @@ def test_filter_scan_plus_rescoring_is_bitwise_the_single_query_scan(batch, dtyp
 
 
 def test_filter_path_falls_back_per_query_on_massive_ties():
-    # query 0 ties on > 8192 M-tiles (its candidate list overflows -> flagged -> stored-score pass);
+    # query 0 ties on > 16384 M-tiles (its candidate list overflows -> flagged -> stored-score pass);
     # the other queries of the batch stay on the filter path.  Both kinds must be exact.
     V = synth.unit_rows(200_000, 384, 91)
-    V[::20] = V[3]                               # 10000 copies of row 3, spread over 10000 M-tiles
+    V[::10] = V[3]                               # 20000 copies of row 3, spread over 20000 M-tiles
     Q = synth.unit_rows(20, 384, 92)
     Q[0] = V[3]
     ix = ProductIndex(V)
     rows, scores = ix.dense_topk(Q, 150)
-    assert rows[0].tolist() == sorted({3} | set(range(0, 20 * 150, 20)))[:150]   # equal scores -> ascending row
+    assert rows[0].tolist() == sorted({3} | set(range(0, 10 * 150, 10)))[:150]   # equal scores -> ascending row
     assert np.all(scores[0] == scores[0][0])
     r1, s1 = ix.dense_topk(Q[5:6], 150)          # a query that stayed on the filter path
     assert np.array_equal(r1[0], rows[5]) and np.array_equal(s1[0], scores[5])
