@@ -337,3 +337,58 @@ print("chain-ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "chain-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_exact_split_operand_scans_in_a_subprocess():
+    """RR_SCAN_EXACT=1 turns the filter scan off: batches run the split-operand scans (16x16x32 tiles up
+    to 16 queries, 32x32x16 beyond) with their own two-pass selection and bit-exact rescoring -- the
+    path a matrix without a finite row-norm bound takes.  Read once per process: child process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys; sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np
+from oracle import dense as OD
+from parity import assert_topk_matches
+from review_recommender_amd import synth
+from review_recommender_amd.index import ProductIndex
+for dtype in ("f32", "bf16"):
+    V = synth.unit_rows(150_037, 384, 171)
+    V[149_990:150_030] = V[7]                     # ties in the ragged tail
+    Vo = OD.round_to_bf16(V) if dtype == "bf16" else V
+    ix = ProductIndex.from_rows(V, dtype=dtype)
+    for batch in (9, 40, 64):
+        Q = synth.unit_rows(batch, 384, 172 + batch)
+        Q[2] = V[7]
+        rows, scores = ix.dense_topk(Q, 150)
+        assert ix.select_trace()[0] == 2, ix.select_trace()[:4]       # two-pass, no stored scores
+        for i in (0, 2, batch - 1):
+            assert_topk_matches(rows[i], scores[i], OD.sims_float64(Vo, Q[i]), 150)
+        ix.set_scan_mode(True)
+        r1, s1 = ix.dense_topk(Q, 150)                                # the stored-score pass: bit-equal
+        ix.set_scan_mode(False)
+        assert np.array_equal(r1, rows) and np.array_equal(s1.view(np.uint32), scores.view(np.uint32))
+print("exact-ok")
+'''
+    env = dict(os.environ, RR_SCAN_EXACT="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "exact-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("batch", [40, 130])
+def test_filter_scan_ragged_tail_and_ties(batch):
+    # just above the 8 x pool tiles the filter path asks for, last tile 37 rows, ties that straddle it
+    n = 8 * 150 * 64 + 37
+    V = synth.unit_rows(n, 384, 500)
+    V[n - 50:n - 5] = V[5]
+    Q = synth.unit_rows(batch, 384, 501)
+    Q[7] = V[5]
+    ix = ProductIndex(V)
+    rows, scores = check_against_oracle(V, Q[:9], 150, index=ix)
+    rows_all, scores_all = ix.dense_topk(Q, 150)
+    assert np.array_equal(rows_all[:9], rows) and np.array_equal(scores_all[:9].view(np.uint32), scores.view(np.uint32))
+    dup = [5] + list(range(n - 50, n - 5))
+    assert rows_all[7][:46].tolist() == sorted(dup)
+    ix.close()
