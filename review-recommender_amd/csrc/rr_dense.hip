@@ -778,6 +778,8 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
     const int gpw = G.gpw > 1 ? G.gpw : 1;
     const int ng = G.n_waves * gpw;
     int phase = 0;
+    const long long c0 = clock64();
+    long long c1 = c0, c2 = c0;
     if (tid < 4) counters[tid] = 0;
     __syncthreads();
     bool ok = ng <= RR_SEL_RK * RR_SEL_THREADS && ng > pool;   // few groups = a small matrix: take the stored path
@@ -796,32 +798,58 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
             if (counters[0] > RR_SEL_LCAP) ok = false;
         }
     }
+    c1 = clock64();
     if (ok) {
         const int C = (int)G.tiles_per_group;
         const int64_t n2 = (int64_t)counters[0] * C;
         const f32x4* mm4 = reinterpret_cast<const f32x4*>(mmax);
+        if (G.mm_pairs == 2) {
+            // 8-row M-tiles (filter scan): two 32-row tiles x four bf16 maxima per 64-row tile.  Four tiles per
+            // thread and pass, all eight loads issued before the first is looked at (the loop is otherwise one
+            // HBM round trip per pass).
+            constexpr int U = 4;
+            const int n2i = (int)n2;                                       // (<= 4096 groups x tiles per group)
+            for (int i0 = tid; i0 < n2i; i0 += U * RR_SEL_THREADS) {
+                int64_t tt[U];
+                uint2 w0[U], w1[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * RR_SEL_THREADS;
+                    tt[u] = -1;
+                    if (i < n2i) {
+                        const int g = (int)list2[i / C], k = g % gpw, j = i % C;
+                        const int64_t in_run = (int64_t)k * C + j;             // tile of the wave's run
+                        const int64_t t = (int64_t)(g / gpw) * G.tiles_per_wave + in_run;
+                        if (in_run < G.tiles_per_wave && t < G.n_tiles) tt[u] = t;
+                    }
+                    const int64_t ts = tt[u] < 0 ? 0 : tt[u];
+                    w0[u] = reinterpret_cast<const uint2*>(mmax)[(2 * ts) * QS + q];
+                    w1[u] = reinterpret_cast<const uint2*>(mmax)[(2 * ts + 1) * QS + q];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (tt[u] < 0) continue;
+                    const float v8[8] = {__uint_as_float(w0[u].x << 16), __uint_as_float(w0[u].x & 0xFFFF0000u),
+                                         __uint_as_float(w0[u].y << 16), __uint_as_float(w0[u].y & 0xFFFF0000u),
+                                         __uint_as_float(w1[u].x << 16), __uint_as_float(w1[u].x & 0xFFFF0000u),
+                                         __uint_as_float(w1[u].y << 16), __uint_as_float(w1[u].y & 0xFFFF0000u)};
+#pragma unroll
+                    for (int sub = 0; sub < 8; ++sub) {
+                        if (rr_f2key(v8[sub]) >= open) {
+                            const uint32_t slot = atomicAdd(&counters[1], 1u);
+                            if (slot < RR_X3_MCAP) out_mtiles[(int64_t)q * RR_X3_MCAP + slot] = (uint32_t)(tt[u] * 8 + sub);
+                        }
+                    }
+                }
+            }
+        } else
         for (int64_t i = tid; i < n2; i += RR_SEL_THREADS) {
             const int g = (int)list2[i / C], k = g % gpw, j = (int)(i % C);
             const int64_t in_run = (int64_t)k * C + j;                     // tile of the wave's run
             const int64_t t = (int64_t)(g / gpw) * G.tiles_per_wave + in_run;
             if (in_run >= G.tiles_per_wave || t >= G.n_tiles) continue;
             float v[4];
-            if (G.mm_pairs == 2) {          // 8-row M-tiles: two 32-row tiles x four bf16 maxima each
-                const uint2 w0 = reinterpret_cast<const uint2*>(mmax)[(2 * t) * QS + q];
-                const uint2 w1 = reinterpret_cast<const uint2*>(mmax)[(2 * t + 1) * QS + q];
-                const float u[8] = {__uint_as_float(w0.x << 16), __uint_as_float(w0.x & 0xFFFF0000u),
-                                    __uint_as_float(w0.y << 16), __uint_as_float(w0.y & 0xFFFF0000u),
-                                    __uint_as_float(w1.x << 16), __uint_as_float(w1.x & 0xFFFF0000u),
-                                    __uint_as_float(w1.y << 16), __uint_as_float(w1.y & 0xFFFF0000u)};
-#pragma unroll
-                for (int sub = 0; sub < 8; ++sub) {
-                    if (rr_f2key(u[sub]) >= open) {
-                        const uint32_t slot = atomicAdd(&counters[1], 1u);
-                        if (slot < RR_X3_MCAP) out_mtiles[(int64_t)q * RR_X3_MCAP + slot] = (uint32_t)(t * 8 + sub);
-                    }
-                }
-                continue;
-            } else if (G.mm_pairs) {
+            if (G.mm_pairs) {
                 const float2 m0 = reinterpret_cast<const float2*>(mmax)[(2 * t) * QS + q];
                 const float2 m1 = reinterpret_cast<const float2*>(mmax)[(2 * t + 1) * QS + q];
                 v[0] = m0.x, v[1] = m0.y, v[2] = m1.x, v[3] = m1.y;
@@ -840,6 +868,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
         __syncthreads();
         if (counters[1] > RR_X3_MCAP) ok = false;
     }
+    c2 = clock64();
     if (tid == 0) {
         out_count[q] = ok ? (int32_t)counters[1] : 0;
         out_tau[q] = tau;
@@ -848,7 +877,9 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
         dbg[q * 16 + 1] = (int32_t)counters[0];
         dbg[q * 16 + 2] = (int32_t)counters[1];
         dbg[q * 16 + 3] = 0;
-        for (int i = 4; i < 16; ++i) dbg[q * 16 + i] = -1;
+        dbg[q * 16 + 4] = (int32_t)(c1 - c0);         // shader cycles: threshold + group list | M-tile list
+        dbg[q * 16 + 5] = (int32_t)(c2 - c1);
+        for (int i = 6; i < 16; ++i) dbg[q * 16 + i] = -1;
     }
 }
 

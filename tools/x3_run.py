@@ -16,4 +16,4 @@ for _ in range(reps):
     _lib.check(lib.rr_dense_topk_dev(ix.handle, C.c_void_p(q.data_ptr()), b, 150, C.c_void_p(rows.data_ptr()),
                                      C.c_void_p(sc.data_ptr()), None), "rr_dense_topk_dev")
 torch.cuda.synchronize()
-print("done", ix.select_trace()[:4])
+print("done", ix.select_trace()[:8])
