@@ -220,6 +220,9 @@ int rr_reviews_best_dev(rr_reviews* rv, const float* d_queries, int32_t n_querie
  * (bit 0: no operand split, bit 1: no B-fragment reads, bit 2: no MFMA, bit 3: no lane swap).
  * Leaves garbage in the scan scratch; never part of a search. */
 int rr_debug_scan_x3w(rr_index* ix, int32_t variant, int32_t reps, float* out_ms);
+/* The same for the 128-query fp32 filter scan (bit 0: no epilogue, bit 1: no B-fragment reads, bit 2: no
+ * MFMA, bit 3: no lane swaps / conversions). */
+int rr_debug_scan_flt(rr_index* ix, int32_t variant, int32_t reps, float* out_ms);
 
 /* Stream helpers for callers that chain *_dev calls. */
 int rr_index_stream(rr_index* ix, void** out_stream);

@@ -21,8 +21,8 @@ struct rr_scan_geom {
     int64_t n_pad;            // 64 * n_tiles
     int32_t mm_pairs;         // M-tile maxima of the two-pass path: 0 = [tile][Q][4] (rr_scan_mfma_x3),
                               // 1 = [32-row tile][Q][2] (rr_scan_x3w: whole lines per store),
-                              // 2 = [32-row tile][Q][4 x bf16, rounded up] of 8-ROW M-tiles (rr_scan_flt): the listed ids
-                              //     and the rescoring scratch are then per 8 rows
+                              // 3 = [32-row tile][Q] 4 bytes (rr_scan_flt): bf16 tile maximum rounded up + four 4-bit gaps of
+                              //     its 8-ROW M-tiles; the listed ids and the rescoring scratch are then per 8 rows
     int32_t gpw;              // groups per wave (0 or 1: the wave's whole run is one group); rr_scan_flt cuts a run into
     int64_t tiles_per_group;  //   gpw sub-runs of tiles_per_group tiles, group g = wave * gpw + k: fewer tiles to open per group
 };
@@ -45,6 +45,7 @@ struct rr_x3_scratch {           // (every array RR_FLT_MAXQ queries long)
     uint32_t* tau;               // [q] key threshold of the query's rows
     int32_t* fb;                 // [q] 1 = the query needs the stored-score fallback
     float* eps;                  // [q] filter scan: error bound of the query's approximate scores
+    float* step;                 // [1] filter scan: resolution of the packed 8-row gaps
     float* sc;                   // [q][RR_X3_MCAP][16] rescored rows
 };
 rr_x3_scratch rr_x3_scratch_of(const rr_index* ix);
@@ -52,7 +53,7 @@ size_t rr_x3_scratch_bytes();
 // `eps` (device, per query, may be null): the scan's scores are approximations within eps of the scores
 // the rescoring will produce; M-tiles are then opened down to tau - 2 eps and rows kept down to tau - eps.
 void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st,
-                             const float* eps = nullptr);
+                             const float* eps = nullptr, const float* step = nullptr);
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st);
 // Waves a kernel can keep resident on the device (occupancy x CUs x waves per workgroup).

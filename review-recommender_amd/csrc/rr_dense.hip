@@ -767,7 +767,8 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
 __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
     rr_scan_geom G, const float* __restrict__ mmax, const uint32_t* __restrict__ smax, int pool,
     uint32_t* __restrict__ out_mtiles, int32_t* __restrict__ out_count, uint32_t* __restrict__ out_tau,
-    int32_t* __restrict__ fb, int32_t* __restrict__ dbg, const float* __restrict__ eps) {
+    int32_t* __restrict__ fb, int32_t* __restrict__ dbg, const float* __restrict__ eps,
+    const float* __restrict__ step_ptr) {
     __shared__ uint32_t cnt[2][3][16];
     __shared__ uint32_t counters[4];
     __shared__ uint32_t list2[RR_SEL_LCAP];
@@ -803,15 +804,17 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
         const int C = (int)G.tiles_per_group;
         const int64_t n2 = (int64_t)counters[0] * C;
         const f32x4* mm4 = reinterpret_cast<const f32x4*>(mmax);
-        if (G.mm_pairs == 2) {
-            // 8-row M-tiles (filter scan): two 32-row tiles x four bf16 maxima per 64-row tile.  Four tiles per
-            // thread and pass, all eight loads issued before the first is looked at (the loop is otherwise one
-            // HBM round trip per pass).
+        if (G.mm_pairs == 3) {
+            // 8-row M-tiles (filter scan): per 32-row tile and query one word = bf16 tile maximum (rounded up) + four
+            // 4-bit gaps; upper bound of M-tile g = max - code_g * step.  Four 64-row tiles per thread and pass, all
+            // loads issued before the first is looked at (the loop is otherwise one HBM round trip per pass).
             constexpr int U = 4;
+            const float step = *step_ptr;
+            const float openf = open <= 0x007FFFFFu ? -INFINITY : rr_key2f(open);   // (keys below key(-inf) are not scores)
             const int n2i = (int)n2;                                       // (<= 4096 groups x tiles per group)
             for (int i0 = tid; i0 < n2i; i0 += U * RR_SEL_THREADS) {
                 int64_t tt[U];
-                uint2 w0[U], w1[U];
+                uint32_t w0[U], w1[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = i0 + u * RR_SEL_THREADS;
@@ -823,21 +826,24 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
                         if (in_run < G.tiles_per_wave && t < G.n_tiles) tt[u] = t;
                     }
                     const int64_t ts = tt[u] < 0 ? 0 : tt[u];
-                    w0[u] = reinterpret_cast<const uint2*>(mmax)[(2 * ts) * QS + q];
-                    w1[u] = reinterpret_cast<const uint2*>(mmax)[(2 * ts + 1) * QS + q];
+                    w0[u] = reinterpret_cast<const uint32_t*>(mmax)[(2 * ts) * QS + q];
+                    w1[u] = reinterpret_cast<const uint32_t*>(mmax)[(2 * ts + 1) * QS + q];
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (tt[u] < 0) continue;
-                    const float v8[8] = {__uint_as_float(w0[u].x << 16), __uint_as_float(w0[u].x & 0xFFFF0000u),
-                                         __uint_as_float(w0[u].y << 16), __uint_as_float(w0[u].y & 0xFFFF0000u),
-                                         __uint_as_float(w1[u].x << 16), __uint_as_float(w1[u].x & 0xFFFF0000u),
-                                         __uint_as_float(w1[u].y << 16), __uint_as_float(w1[u].y & 0xFFFF0000u)};
 #pragma unroll
-                    for (int sub = 0; sub < 8; ++sub) {
-                        if (rr_f2key(v8[sub]) >= open) {
-                            const uint32_t slot = atomicAdd(&counters[1], 1u);
-                            if (slot < RR_X3_MCAP) out_mtiles[(int64_t)q * RR_X3_MCAP + slot] = (uint32_t)(tt[u] * 8 + sub);
+                    for (int half = 0; half < 2; ++half) {
+                        const uint32_t w = half ? w1[u] : w0[u];
+                        const float mx = __uint_as_float(w << 16);
+                        if (!(mx >= openf)) continue;                          // the whole 32-row tile is below the threshold
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float bound = mx - (float)((w >> (16 + 4 * g)) & 15u) * step;
+                            if (bound >= openf) {
+                                const uint32_t slot = atomicAdd(&counters[1], 1u);
+                                if (slot < RR_X3_MCAP) out_mtiles[(int64_t)q * RR_X3_MCAP + slot] = (uint32_t)(tt[u] * 8 + 4 * half + g);
+                            }
                         }
                     }
                 }
@@ -896,7 +902,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
     if (tid < 2) counters[tid] = 0;
     __syncthreads();
     const uint32_t tau = tau_of[q];
-    const int sh = G.mm_pairs == 2 ? 3 : 4;           // rows per listed M-tile: 8 or 16
+    const int sh = G.mm_pairs == 3 ? 3 : 4;           // rows per listed M-tile: 8 or 16
     const int n1 = count[q] << sh;
     for (int i = tid; i < n1; i += RR_SEL_THREADS) {
         const int64_t at = (int64_t)q * RR_X3_MCAP + (i >> sh);
@@ -947,17 +953,19 @@ rr_x3_scratch rr_x3_scratch_of(const rr_index* ix) {
     s.tau = reinterpret_cast<uint32_t*>(p);     p += sizeof(uint32_t) * RR_FLT_MAXQ;
     s.fb = reinterpret_cast<int32_t*>(p);       p += sizeof(int32_t) * RR_FLT_MAXQ;
     s.eps = reinterpret_cast<float*>(p);        p += sizeof(float) * RR_FLT_MAXQ;
+    s.step = reinterpret_cast<float*>(p);       p += 16;
     s.sc = reinterpret_cast<float*>(p);
     return s;
 }
 size_t rr_x3_scratch_bytes() {
-    return sizeof(uint32_t) * RR_FLT_MAXQ * RR_X3_MCAP + 4 * sizeof(int32_t) * RR_FLT_MAXQ +
+    return sizeof(uint32_t) * RR_FLT_MAXQ * RR_X3_MCAP + 4 * sizeof(int32_t) * RR_FLT_MAXQ + 16 +
            sizeof(float) * (size_t)RR_FLT_MAXQ * RR_X3_MCAP * 16;
 }
-void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st, const float* eps) {
+void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st, const float* eps,
+                             const float* step) {
     const rr_x3_scratch s = rr_x3_scratch_of(ix);
     hipLaunchKernelGGL(rr_select_mtiles, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_gmax, ix->d_smax, pool,
-                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps);
+                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps, step);
 }
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st) {

@@ -75,6 +75,22 @@ __global__ __launch_bounds__(64) void rr_flt_prep_queries(const float* __restric
         eps[slot] = 1.01f * (B.row_delta * sqrtf(sr) + B.row_norm * sqrtf(sd) + 6.1035156e-5f * B.row_norm * sqrtf(ss));
 }
 
+// step = half the smallest finite positive eps of the launch's queries (0: none) -> eps[slot_of_step]
+__global__ __launch_bounds__(128) void rr_flt_gap_step(const float* __restrict__ eps, int nq, float* __restrict__ out) {
+    float e = threadIdx.x < nq ? eps[threadIdx.x] : INFINITY;
+    e = (e > 0.f && e < 3.0e38f) ? e : INFINITY;
+    e = fminf(e, __shfl_xor(e, 32, 64));
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) e = fminf(e, __shfl_xor(e, m, 64));
+    __shared__ float w[2];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fminf(w[0], w[1]);
+        *out = m < 3.0e38f ? 0.5f * m : 0.f;
+    }
+}
+
 // max over rows of ||a|| and of ||a - bf16(a)||, as the bits of non-negative floats (atomicMax on uint).
 // 16 lanes per row, 16-byte loads (four rows per wave instruction), 64 rows per wave.
 template <bool A_BF16>
@@ -127,10 +143,12 @@ __global__ __launch_bounds__(256) void rr_row_norm_max(const void* __restrict__ 
 #ifndef RR_FLT_ONE_WAVE
 #define RR_FLT_ONE_WAVE 0
 #endif
-template <int NQ2, bool A_BF16>
+// DBG != 0: timing-only ablations (rr_debug_scan_flt, tools/flt_ablate.py; wrong results): bit 0 no epilogue
+// (accumulators kept alive), bit 1 no B-fragment reads, bit 2 no MFMAs, bit 3 no lane swaps / conversions, bit 4 no M-tile maxima stores.
+template <int NQ2, bool A_BF16, int DBG = 0>
 __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 1 : 2)) void rr_scan_flt(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [32*NQ2][48] units
-    float* __restrict__ gmax, uint32_t* __restrict__ smax) {
+    float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ step_ptr) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
     constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
@@ -174,11 +192,13 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
 
     int qlane = c * RR_FLT_QSTRIDE + h;               // 16-byte unit index into qs: + 32 t * QSTRIDE + 2 * kk
     float gm[NQ2];                                    // running maximum of the current group (sub-run of tiles)
-    uint2 pend[NQ2];                                  // 8-row maxima of the 32-row tile just finished (4 x bf16), stored one tile late
+    uint32_t pend[NQ2];                               // packed maxima of the 32-row tile just finished, stored one tile late
+    const float step = *step_ptr;                     // resolution of the 8-row gaps (half the smallest eps of the launch)
+    const float inv_step = step > 0.f ? 0.9999f / step : 0.f;    // (0.9999: the decoded bound never rounds below the maximum)
 #pragma unroll
     for (int t = 0; t < NQ2; ++t) {
         gm[t] = -INFINITY;
-        pend[t] = uint2{0xFF80FF80u, 0xFF80FF80u};    // -inf
+        pend[t] = 0x0000FF80u;                        // -inf, gaps 0
     }
     auto read_q = [&](int t, int kk) { return __builtin_bit_cast(bf16x8, qs[qlane + 32 * t * RR_FLT_QSTRIDE + 2 * kk]); };
     // fp32 pair (lo, hi = dims 8h .. 8h+7 of the K-step) -> one bf16x8 operand, round to nearest even
@@ -234,23 +254,28 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                 const bool swap = A_BF16 ? (s2 % 2 == 0) : true;          // it starts a new pair of the ring
                 const int np = A_BF16 ? s2 / 2 : s2;
                 constexpr int REFILL_SLOT = 3 / VPS;                      // the slot that issues the last lane swap
+                constexpr int STORE_STEP = A_BF16 ? 10 : 5;               // the K-step after the first burst (np == 5)
                 if (swap && (np == 6 || np == 0)) {
                     // ring waits and deferred maxima stores exactly as in rr_scan_x3w
-                    if (p == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + NQ2) : "memory");
+                    // (younger than what the wait needs: the other half's burst, and for the segment's second wait
+                    //  the NQ2 maxima stores issued during the K-step after the first burst, see below)
+                    if (p == 0 && (np == 0 || s > STORE_STEP) && !(DBG & 16)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + NQ2) : "memory");
                     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
                     for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(a[(np / 6) * 12 + j]));
                 }
 #pragma unroll
                 for (int j = 0; j < NQ2; ++j) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[cb][j], acc[j], 0, 0, 0);
-                    if (swap) {
+                    if (DBG & 4) asm volatile("" :: "v"(af), "v"(qf[cb][j]));
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[cb][j], acc[j], 0, 0, 0);
+                    if (swap && !(DBG & 8)) {
 #pragma unroll
                         for (int k = VPS * j; k < VPS * j + VPS; ++k) valu_op(k, a[2 * np], a[2 * np + 1]);
                     }
                     // B fragment of the K-step after next, into the register the MFMA above just consumed: two
                     // K-steps (2 NQ2 MFMA slots) of lead instead of one (s_waitcnt lgkmcnt sat in front of every MFMA)
-                    if (LEAD == 2) qf[cb][j] = read_q(j, kk3);
+                    if (DBG & 2) {
+                    } else if (LEAD == 2) qf[cb][j] = read_q(j, kk3);
                     else qf[cb ^ 1][j] = read_q(j, kk3);
                     if (swap && (np == 5 || np == 11) && j == REFILL_SLOT) {
                         // the lane swaps of this half's last pair are issued: re-load the half
@@ -258,21 +283,31 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                         for (int u = 0; u < 12; u += 2) RR_FLT_LOAD(a[(np / 6) * 12 + u], (np / 6) * 12 + u);
 #pragma unroll
                         for (int u = 1; u < 12; u += 2) RR_FLT_LOAD(a[(np / 6) * 12 + u], (np / 6) * 12 + u);
-                        if (p == 0 && np == 5) {
-                            // NQ2 stores, always (the ring waits count them): the previous M-tile's maxima.  First
-                            // M-tile of the wave: nothing pending -- the stores go to its own slot, overwritten by
-                            // this wave one M-tile later.
-                            const int64_t mprev = mt > m0 ? mt - 1 : mt;
-#pragma unroll
-                            for (int t = 0; t < NQ2; ++t)
-                                if (h == 0) *reinterpret_cast<uint2*>(gmax + ((mprev * QN + 32 * t + c) << 1)) = pend[t];
-                        }
+                    }
+                    // The previous M-tile's maxima (NQ2 stores, always: the ring waits count them), one per MFMA slot
+                    // of the K-step after the first burst.  First M-tile of the wave: nothing pending -- the stores
+                    // go to its own slot, overwritten by this wave one M-tile later.
+                    // What these stores cost (tools/flt_ablate.py, 128 queries, a slow box of the pool): 3.03 ms with
+                    // them, 2.49 ms (6.2 TB/s) without -- everything else in the kernel is hidden behind the HBM
+                    // stream.  The cost follows the BYTES (320 MB per scan, 2 % of the traffic, 20 % of the time:
+                    // neither placement nor halving the instruction count moves it): isolated line write-backs
+                    // into a saturated read stream.
+                    if (p == 0 && s == STORE_STEP && !(DBG & 16)) {
+                        const int64_t mprev = mt > m0 ? mt - 1 : mt;
+                        if (h == 0) reinterpret_cast<uint32_t*>(gmax)[mprev * QN + 32 * j + c] = pend[j];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (A_BF16) af = __builtin_bit_cast(bf16x8, (s2 % 2 == 0) ? lo : hi);
                 else af = __builtin_bit_cast(bf16x8, nxt);
             }
+        }
+        if (DBG & 1) {
+#pragma unroll
+            for (int t = 0; t < NQ2; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) asm volatile("" :: "v"(acc[t][e]));
+            continue;
         }
         // lane (c, h), register 4g + i: row 8g + 4h + i of the M-tile, query 32t + c
         const int64_t rbase = mt * 32 + 4 * h;
@@ -287,23 +322,28 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                 if (!full) v = rr_x3_canon(v, rbase + 8 * g, G.n_rows);            // (fmaxf drops a NaN by itself)
                 m8[g] = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
             }
-            uint32_t pk[2];
+            // the other k half's rows (lane l ^ 32)
 #pragma unroll
-            for (int g2 = 0; g2 < 2; ++g2) {
-                // the other k half's rows (lane l ^ 32), then both maxima as bf16 ROUNDED UP: the filter only asks
-                // "can this M-tile hold a score >= threshold", so an upper bound in 16 bits is all it needs
-                float a0 = m8[2 * g2], a1 = m8[2 * g2 + 1];
-                const auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a0), false, false);
-                const auto r1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1), __float_as_uint(a1), false, false);
-                a0 = fmaxf(__uint_as_float(r0[0]), __uint_as_float(r0[1]));
-                a1 = fmaxf(__uint_as_float(r1[0]), __uint_as_float(r1[1]));
-                gm[t] = fmaxf(gm[t], fmaxf(a0, a1));
-                const uint32_t b0 = __float_as_uint(a0), b1 = __float_as_uint(a1);
-                const uint32_t u0 = (b0 >> 31) ? (b0 >> 16) : ((b0 + 0xFFFFu) >> 16);     // toward +inf; +-inf stay
-                const uint32_t u1 = (b1 >> 31) ? (b1 >> 16) : ((b1 + 0xFFFFu) >> 16);
-                pk[g2] = u0 | (u1 << 16);
+            for (int g = 0; g < 4; ++g) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m8[g]), __float_as_uint(m8[g]), false, false);
+                m8[g] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
             }
-            pend[t] = uint2{pk[0], pk[1]};
+            // 4 bytes per (32-row tile, query): the tile maximum as bf16 ROUNDED UP + for each 8-row M-tile how far
+            // below it its own maximum sits, in units of `step`, ROUNDED DOWN to 4 bits (15 = "at least 15 steps").
+            // The filter only asks "can this M-tile hold a score >= threshold": the decoded value
+            // max_up - code * step is an upper bound of the M-tile's maximum, at most one step + 2^-8 loose.
+            const float m32 = fmaxf(fmaxf(m8[0], m8[1]), fmaxf(m8[2], m8[3]));
+            gm[t] = fmaxf(gm[t], m32);
+            const uint32_t b = __float_as_uint(m32);
+            uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);           // toward +inf; +-inf stay
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float gap = (m32 - m8[g]) * inv_step;                          // >= 0; inf - inf = NaN -> code 0
+                uint32_t code = (uint32_t)fminf(gap, 15.f);                          // (fminf drops a NaN: 15; then m8 = m32 = -inf anyway)
+                code = gap == gap ? code : 0u;
+                word |= code << (16 + 4 * g);
+            }
+            pend[t] = word;
         }
         {   // group k of the wave = tiles [t0 + k Cg, t0 + (k + 1) Cg) of its run.  Its maximum is stored at once:
             // the next ring wait then covers a fresh store and stalls (~2 us), once per ~19 tiles.
@@ -322,7 +362,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     if (h == 0) {
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
-            *reinterpret_cast<uint2*>(gmax + (((m1 - 1) * QN + 32 * t + c) << 1)) = pend[t];
+            reinterpret_cast<uint32_t*>(gmax)[(m1 - 1) * QN + 32 * t + c] = pend[t];
         }
     }
 }
@@ -423,31 +463,39 @@ static int rr_flt_get_bounds(rr_index* ix, hipStream_t st, rr_flt_bounds* out) {
 }
 
 template <int NQ2, bool A_BF16>
-static int rr_dense_chunk_flt_t(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
-                                float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
+static rr_scan_geom rr_flt_geom(rr_index* ix) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
-    constexpr int QN = 32 * NQ2;
     static int waves = 0;
     if (!waves) waves = rr_resident_waves((const void*)rr_scan_flt<NQ2, A_BF16>, THREADS, ix->device);
     rr_scan_geom G = rr_make_geom(ix, waves / 4);
-    G.qs = QN;
-    G.mm_pairs = 2;
+    G.qs = 32 * NQ2;
+    G.mm_pairs = 3;
     // selection groups = quarter runs: ~4x fewer tile maxima to open per group (at most 8192 groups)
     G.gpw = RR_MAX_SCAN_WAVES / G.n_waves < 4 ? (RR_MAX_SCAN_WAVES / G.n_waves < 1 ? 1 : RR_MAX_SCAN_WAVES / G.n_waves) : 4;
     if (G.gpw > G.tiles_per_wave) G.gpw = (int32_t)G.tiles_per_wave;
     G.tiles_per_group = (G.tiles_per_wave + G.gpw - 1) / G.gpw;
     G.gpw = (int32_t)((G.tiles_per_wave + G.tiles_per_group - 1) / G.tiles_per_group);     // no empty trailing groups
+    return G;
+}
+
+template <int NQ2, bool A_BF16>
+static int rr_dense_chunk_flt_t(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+                                float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
+    constexpr int THREADS = RR_FLT_THREADS(NQ2);
+    constexpr int QN = 32 * NQ2;
+    const rr_scan_geom G = rr_flt_geom<NQ2, A_BF16>(ix);
     unsigned short* plane = reinterpret_cast<unsigned short*>(ix->d_qplanes);
     const rr_x3_scratch X = rr_x3_scratch_of(ix);
     RR_HIP_TRY(hipMemsetAsync(ix->d_smax, 0, sizeof(uint32_t) * (size_t)G.n_waves * G.gpw * QN, st));   // (empty groups: key 0)
     hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, X.eps, bounds,
                        A_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL);
+    hipLaunchKernelGGL(rr_flt_gap_step, dim3(1), dim3(128), 0, st, X.eps, nq, X.step);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     const int slot = rr_scan_events_begin(ix, st);
     hipLaunchKernelGGL((rr_scan_flt<NQ2, A_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
-                       reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax);
+                       reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax, X.step);
     rr_scan_events_end(ix, slot, st);
-    rr_launch_select_mtiles(ix, G, nq, pool, st, X.eps);
+    rr_launch_select_mtiles(ix, G, nq, pool, st, X.eps, X.step);
     hipLaunchKernelGGL((rr_rescore_chain<A_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
                        X.mtiles, X.count, X.fb, X.sc);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st);
@@ -483,4 +531,52 @@ int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t
                  : rr_dense_chunk_flt_t<2, false>(ix, d_q, nq, pool, d_rows, d_scores, nb, st);
     return b ? rr_dense_chunk_flt_t<4, true>(ix, d_q, nq, pool, d_rows, d_scores, nb, st)
              : rr_dense_chunk_flt_t<4, false>(ix, d_q, nq, pool, d_rows, d_scores, nb, st);
+}
+
+// Timing-only ablations of the 128-query fp32 filter scan (tools/flt_ablate.py).  Garbage in the scratch afterwards.
+template <int DBG>
+static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
+    constexpr int THREADS = RR_FLT_THREADS(4);
+    const rr_scan_geom G = rr_flt_geom<4, false>(ix);
+    const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float total = 0.f;
+    for (int r = 0; r < reps + 1; ++r) {
+        hipEventRecord(e0, st);
+        hipLaunchKernelGGL((rr_scan_flt<4, false, DBG>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
+                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).step);
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r) total += ms;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return total / reps;
+}
+
+extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float* out_ms) {
+    RR_REQUIRE(ix && out_ms && ix->dtype == RR_DTYPE_F32 && ix->dim_pad == 384, "fp32 index of dim 384 expected");
+    RR_REQUIRE(ix->scratch_q >= 64, "run a batched search first (allocates the scratch)");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    hipStream_t st = nullptr;
+    switch (dbg) {
+        case 0: *out_ms = rr_debug_time_flt<0>(ix, st, reps); break;
+        case 1: *out_ms = rr_debug_time_flt<1>(ix, st, reps); break;
+        case 2: *out_ms = rr_debug_time_flt<2>(ix, st, reps); break;
+        case 4: *out_ms = rr_debug_time_flt<4>(ix, st, reps); break;
+        case 8: *out_ms = rr_debug_time_flt<8>(ix, st, reps); break;
+        case 3: *out_ms = rr_debug_time_flt<3>(ix, st, reps); break;
+        case 7: *out_ms = rr_debug_time_flt<7>(ix, st, reps); break;
+        case 15: *out_ms = rr_debug_time_flt<15>(ix, st, reps); break;
+        case 16: *out_ms = rr_debug_time_flt<16>(ix, st, reps); break;
+        case 31: *out_ms = rr_debug_time_flt<31>(ix, st, reps); break;
+        case 32: *out_ms = rr_debug_time_flt<32>(ix, st, reps); break;
+        default: RR_REQUIRE(false, "unknown ablation %d", dbg);
+    }
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
 }
