@@ -4,7 +4,7 @@ import csv, glob, json, sys
 fetch_dir, write_dir, B, kern = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 out = {}
 for d, c in ((fetch_dir, 'FETCH_SIZE'), (write_dir, 'WRITE_SIZE')):
-    f = glob.glob(f'{d}/**/*counter_collection.csv', recursive=True)[0]
+    f = max(glob.glob(f'{d}/**/*counter_collection.csv', recursive=True), key=__import__('os').path.getmtime)   # newest pass
     vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f)) if kern in r['Kernel_Name'] and r['Counter_Name'] == c]
     out[c] = {'dispatches': len(vals), 'mean_KB': sum(vals) / len(vals), 'min_KB': min(vals), 'max_KB': max(vals)}
 fetch = out['FETCH_SIZE']['mean_KB'] * 1024 * 2
