@@ -96,10 +96,10 @@ int rr_index_last_scan_ms(rr_index* ix, float* out_ms);
 /* Every scan launch is bracketed by a HIP event pair on its stream (ring of 512).
  * Drains the pairs recorded since the last call: total ms and launch count. */
 int rr_index_scan_stats(rr_index* ix, double* out_total_ms, int64_t* out_launches);
-/* Path taken by the last top-pool selection for its first query: out4 = {1 if the
- * LDS-resident 3-level path finished (2: the two-pass rescoring path; 0: generic radix fallback), groups opened, tiles
- * opened, candidate rows}, out16[4..10] = shader-clock cycles of the selection's phases.
- * Diagnostic: lets tests assert the fast path is the one running. */
+/* Path taken by the last top-pool selection for its first query: out16[0] = 2: M-tile maxima + rescoring
+ * (the batched paths), 1: stored scores through the LDS-resident 3-level selection, 0: generic radix
+ * fallback; [1..3] = groups opened, (M-)tiles opened, candidate rows; [4..] = shader-clock cycles of the
+ * selection's phases (-1: unused).  Diagnostic: lets tests assert which path ran. */
 int rr_index_select_trace(rr_index* ix, int32_t* out16);
 /* Diagnostic switch of the batched (5..64 query) scan.  RR_SCAN_MODE_DEFAULT: the scan keeps only
  * M-tile maxima and the candidate M-tiles are rescored (select trace out16[0] == 2), with the
