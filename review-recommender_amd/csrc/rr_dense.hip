@@ -806,7 +806,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
         const f32x4* mm4 = reinterpret_cast<const f32x4*>(mmax);
         if (G.mm_pairs == 3) {
             // 8-row M-tiles (filter scan): per 32-row tile and query one word = bf16 tile maximum (rounded up) + four
-            // 4-bit gaps; upper bound of M-tile g = max - code_g * step.  Four 64-row tiles per thread and pass, all
+            // 4-bit gap codes; upper bound of M-tile g = max - steps(code_g) * step.  Four 64-row tiles per thread and pass, all
             // loads issued before the first is looked at (the loop is otherwise one HBM round trip per pass).
             constexpr int U = 4;
             const float step = *step_ptr;
@@ -839,7 +839,9 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
                         if (!(mx >= openf)) continue;                          // the whole 32-row tile is below the threshold
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const float bound = mx - (float)((w >> (16 + 4 * g)) & 15u) * step;
+                            const uint32_t code = (w >> (16 + 4 * g)) & 15u;       // 0..12 steps, then >= 16 | 24 | 40
+                            const float steps = code <= 12u ? (float)code : code == 13u ? 16.f : code == 14u ? 24.f : 40.f;
+                            const float bound = mx - steps * step;
                             if (bound >= openf) {
                                 const uint32_t slot = atomicAdd(&counters[1], 1u);
                                 if (slot < RR_X3_MCAP) out_mtiles[(int64_t)q * RR_X3_MCAP + slot] = (uint32_t)(tt[u] * 8 + 4 * half + g);

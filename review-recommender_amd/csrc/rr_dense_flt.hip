@@ -329,17 +329,20 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                 m8[g] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
             }
             // 4 bytes per (32-row tile, query): the tile maximum as bf16 ROUNDED UP + for each 8-row M-tile how far
-            // below it its own maximum sits, in units of `step`, ROUNDED DOWN to 4 bits (15 = "at least 15 steps").
-            // The filter only asks "can this M-tile hold a score >= threshold": the decoded value
-            // max_up - code * step is an upper bound of the M-tile's maximum, at most one step + 2^-8 loose.
+            // below it its own maximum sits, in units of `step`, ROUNDED DOWN to a 4-bit code (0..12 steps, then
+            // >= 16, 24, 40).  The filter only asks "can this M-tile hold a score >= threshold": the decoded value
+            // max_up - steps(code) * step is an upper bound of the M-tile's maximum.
             const float m32 = fmaxf(fmaxf(m8[0], m8[1]), fmaxf(m8[2], m8[3]));
             gm[t] = fmaxf(gm[t], m32);
             const uint32_t b = __float_as_uint(m32);
             uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);           // toward +inf; +-inf stay
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float gap = (m32 - m8[g]) * inv_step;                          // >= 0; inf - inf = NaN -> code 0
-                uint32_t code = (uint32_t)fminf(gap, 15.f);                          // (fminf drops a NaN: 15; then m8 = m32 = -inf anyway)
+                const float gap = (m32 - m8[g]) * inv_step;                          // >= 0, in steps; inf - inf = NaN -> code 0
+                uint32_t code = (uint32_t)fminf(gap, 12.f);                          // 0 .. 12 steps exactly (rounded down), then
+                code = gap >= 16.f ? 13u : code;                                     // "at least 16 | 24 | 40 steps" (RR_FLT_GAP_STEPS):
+                code = gap >= 24.f ? 14u : code;                                     // an ordinary M-tile next to a top row sits ~30 eps
+                code = gap >= 40.f ? 15u : code;                                     // below it and must not be opened with it
                 code = gap == gap ? code : 0u;
                 word |= code << (16 + 4 * g);
             }
