@@ -45,7 +45,6 @@ struct rr_x3_scratch {           // (every array RR_FLT_MAXQ queries long)
     uint32_t* tau;               // [q] key threshold of the query's rows
     int32_t* fb;                 // [q] 1 = the query needs the stored-score fallback
     float* eps;                  // [q] filter scan: error bound of the query's approximate scores
-    float* step;                 // [1] filter scan: resolution of the packed 8-row gaps
     float* sc;                   // [q][RR_X3_MCAP][16] rescored rows
 };
 rr_x3_scratch rr_x3_scratch_of(const rr_index* ix);
@@ -53,7 +52,7 @@ size_t rr_x3_scratch_bytes();
 // `eps` (device, per query, may be null): the scan's scores are approximations within eps of the scores
 // the rescoring will produce; M-tiles are then opened down to tau - 2 eps and rows kept down to tau - eps.
 void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st,
-                             const float* eps = nullptr, const float* step = nullptr);
+                             const float* eps = nullptr);
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st);
 // Waves a kernel can keep resident on the device (occupancy x CUs x waves per workgroup).

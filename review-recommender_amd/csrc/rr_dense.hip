@@ -28,6 +28,7 @@
 
 #include "rr_common.h"
 #include "rr_dense.h"
+#include "rr_x3.h"
 
 #define RR_SEL_THREADS 1024
 #define RR_SEL_GCAP 4096    // slow path: tiles kept in LDS
@@ -767,8 +768,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
 __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
     rr_scan_geom G, const float* __restrict__ mmax, const uint32_t* __restrict__ smax, int pool,
     uint32_t* __restrict__ out_mtiles, int32_t* __restrict__ out_count, uint32_t* __restrict__ out_tau,
-    int32_t* __restrict__ fb, int32_t* __restrict__ dbg, const float* __restrict__ eps,
-    const float* __restrict__ step_ptr) {
+    int32_t* __restrict__ fb, int32_t* __restrict__ dbg, const float* __restrict__ eps) {
     __shared__ uint32_t cnt[2][3][16];
     __shared__ uint32_t counters[4];
     __shared__ uint32_t list2[RR_SEL_LCAP];
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
             // 4-bit gap codes; upper bound of M-tile g = max - steps(code_g) * step.  Four 64-row tiles per thread and pass, all
             // loads issued before the first is looked at (the loop is otherwise one HBM round trip per pass).
             constexpr int U = 4;
-            const float step = *step_ptr;
+            const float step = rr_flt_gap_step(eps, gridDim.x);
             const float openf = open <= 0x007FFFFFu ? -INFINITY : rr_key2f(open);   // (keys below key(-inf) are not scores)
             const int n2i = (int)n2;                                       // (<= 4096 groups x tiles per group)
             for (int i0 = tid; i0 < n2i; i0 += U * RR_SEL_THREADS) {
@@ -955,19 +955,17 @@ rr_x3_scratch rr_x3_scratch_of(const rr_index* ix) {
     s.tau = reinterpret_cast<uint32_t*>(p);     p += sizeof(uint32_t) * RR_FLT_MAXQ;
     s.fb = reinterpret_cast<int32_t*>(p);       p += sizeof(int32_t) * RR_FLT_MAXQ;
     s.eps = reinterpret_cast<float*>(p);        p += sizeof(float) * RR_FLT_MAXQ;
-    s.step = reinterpret_cast<float*>(p);       p += 16;
     s.sc = reinterpret_cast<float*>(p);
     return s;
 }
 size_t rr_x3_scratch_bytes() {
-    return sizeof(uint32_t) * RR_FLT_MAXQ * RR_X3_MCAP + 4 * sizeof(int32_t) * RR_FLT_MAXQ + 16 +
+    return sizeof(uint32_t) * RR_FLT_MAXQ * RR_X3_MCAP + 4 * sizeof(int32_t) * RR_FLT_MAXQ +
            sizeof(float) * (size_t)RR_FLT_MAXQ * RR_X3_MCAP * 16;
 }
-void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st, const float* eps,
-                             const float* step) {
+void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st, const float* eps) {
     const rr_x3_scratch s = rr_x3_scratch_of(ix);
     hipLaunchKernelGGL(rr_select_mtiles, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_gmax, ix->d_smax, pool,
-                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps, step);
+                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps);
 }
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st) {

@@ -75,22 +75,6 @@ __global__ __launch_bounds__(64) void rr_flt_prep_queries(const float* __restric
         eps[slot] = 1.01f * (B.row_delta * sqrtf(sr) + B.row_norm * sqrtf(sd) + 6.1035156e-5f * B.row_norm * sqrtf(ss));
 }
 
-// step = half the smallest finite positive eps of the launch's queries (0: none) -> eps[slot_of_step]
-__global__ __launch_bounds__(128) void rr_flt_gap_step(const float* __restrict__ eps, int nq, float* __restrict__ out) {
-    float e = threadIdx.x < nq ? eps[threadIdx.x] : INFINITY;
-    e = (e > 0.f && e < 3.0e38f) ? e : INFINITY;
-    e = fminf(e, __shfl_xor(e, 32, 64));
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) e = fminf(e, __shfl_xor(e, m, 64));
-    __shared__ float w[2];
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = e;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float m = fminf(w[0], w[1]);
-        *out = m < 3.0e38f ? 0.5f * m : 0.f;
-    }
-}
-
 // max over rows of ||a|| and of ||a - bf16(a)||, as the bits of non-negative floats (atomicMax on uint).
 // 16 lanes per row, 16-byte loads (four rows per wave instruction), 64 rows per wave.
 template <bool A_BF16>
@@ -148,7 +132,7 @@ __global__ __launch_bounds__(256) void rr_row_norm_max(const void* __restrict__ 
 template <int NQ2, bool A_BF16, int DBG = 0>
 __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 1 : 2)) void rr_scan_flt(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [32*NQ2][48] units
-    float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ step_ptr) {
+    float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
     constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
@@ -193,7 +177,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     int qlane = c * RR_FLT_QSTRIDE + h;               // 16-byte unit index into qs: + 32 t * QSTRIDE + 2 * kk
     float gm[NQ2];                                    // running maximum of the current group (sub-run of tiles)
     uint32_t pend[NQ2];                               // packed maxima of the 32-row tile just finished, stored one tile late
-    const float step = *step_ptr;                     // resolution of the 8-row gaps (half the smallest eps of the launch)
+    const float step = rr_flt_gap_step(eps, nq);      // resolution of the 8-row gaps (half the smallest eps of the launch)
     const float inv_step = step > 0.f ? 0.9999f / step : 0.f;    // (0.9999: the decoded bound never rounds below the maximum)
 #pragma unroll
     for (int t = 0; t < NQ2; ++t) {
@@ -363,6 +347,11 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
     if (h == 0) {
+        // groups of this wave that hold no tile (a short last run): key 0 = "nothing here"
+        const int cg = (int)G.tiles_per_group;
+        for (int k = (int)((t1 - t0 + cg - 1) / cg); k < G.gpw; ++k)
+#pragma unroll
+            for (int t = 0; t < NQ2; ++t) smax[(wave * G.gpw + k) * QN + 32 * t + c] = 0u;
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
             reinterpret_cast<uint32_t*>(gmax)[(m1 - 1) * QN + 32 * t + c] = pend[t];
@@ -489,16 +478,14 @@ static int rr_dense_chunk_flt_t(rr_index* ix, const float* d_q, int nq, int pool
     const rr_scan_geom G = rr_flt_geom<NQ2, A_BF16>(ix);
     unsigned short* plane = reinterpret_cast<unsigned short*>(ix->d_qplanes);
     const rr_x3_scratch X = rr_x3_scratch_of(ix);
-    RR_HIP_TRY(hipMemsetAsync(ix->d_smax, 0, sizeof(uint32_t) * (size_t)G.n_waves * G.gpw * QN, st));   // (empty groups: key 0)
     hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, X.eps, bounds,
                        A_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL);
-    hipLaunchKernelGGL(rr_flt_gap_step, dim3(1), dim3(128), 0, st, X.eps, nq, X.step);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     const int slot = rr_scan_events_begin(ix, st);
     hipLaunchKernelGGL((rr_scan_flt<NQ2, A_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
-                       reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax, X.step);
+                       reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax, X.eps, nq);
     rr_scan_events_end(ix, slot, st);
-    rr_launch_select_mtiles(ix, G, nq, pool, st, X.eps, X.step);
+    rr_launch_select_mtiles(ix, G, nq, pool, st, X.eps);
     hipLaunchKernelGGL((rr_rescore_chain<A_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
                        X.mtiles, X.count, X.fb, X.sc);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st);
@@ -549,7 +536,7 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     for (int r = 0; r < reps + 1; ++r) {
         hipEventRecord(e0, st);
         hipLaunchKernelGGL((rr_scan_flt<4, false, DBG>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
-                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).step);
+                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128);
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
         float ms = 0.f;

@@ -69,6 +69,21 @@ int rr_dense_chunk_x3w(rr_index* ix, const float* d_q, int nq, int pool, int64_t
 int rr_dense_chunk_x3w_fallback(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                                 float* d_scores, const int32_t* flags, hipStream_t st);
 
+// Resolution of the filter scan's packed 8-row gaps: half the smallest finite positive error bound of the
+// launch's queries (0: none).  Every wave / workgroup recomputes it from the nq (<= 128) bounds.
+__device__ __forceinline__ float rr_flt_gap_step(const float* __restrict__ eps, int nq) {
+    const int lane = threadIdx.x & 63;
+    float e = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float v = lane + 64 * i < nq ? eps[lane + 64 * i] : INFINITY;
+        e = fminf(e, (v > 0.f && v < 3.0e38f) ? v : INFINITY);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) e = fminf(e, __shfl_xor(e, m, 64));
+    return e < 3.0e38f ? 0.5f * e : 0.f;
+}
+
 // NaN scores and pad rows rank last (rows row0 .. row0+3 of one query)
 __device__ __forceinline__ f32x4 rr_x3_canon(f32x4 v, int64_t row0, int64_t n_rows) {
     v.x = (row0 + 0 < n_rows && v.x == v.x) ? v.x : -INFINITY;
