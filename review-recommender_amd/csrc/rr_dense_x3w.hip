@@ -58,7 +58,7 @@ template <int NQ2, bool A_BF16, bool STORE, int DBG = 0>
 __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr_scan_x3w(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ planes,  // [3][32*NQ2][48] units
     float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax,
-    const int32_t* __restrict__ fallback, int n_flags) {
+    const int32_t* __restrict__ fallback, int n_flags, const float* __restrict__ raw_q = nullptr) {
     constexpr int THREADS = (NQ2 == 2 && !(DBG & 32)) ? 512 : 256;   // (DBG bit 5: one wave per SIMD)
     if (STORE && fallback) {
         int any = 0;
@@ -71,7 +71,37 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
     constexpr int NTERM = A_BF16 ? 3 : 6;
     __shared__ u32x4 qs[3 * QN * RR_X3W_QSTRIDE];
     const int tid = threadIdx.x;
-    if (!(DBG & 128)) {
+    if (raw_q) {
+        // fallback launches: split the fp32 queries here (what rr_split_queries would have left in `planes`,
+        // bit for bit) -- one kernel launch fewer per fallback, which is enqueued behind every filter launch
+        for (int i = tid; i < QN * RR_X3_UNITS; i += THREADS) {
+            const int qn = i / RR_X3_UNITS, u = i % RR_X3_UNITS;
+            u32x4 pl[3];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                float x1[2], x2[2], x3[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int pos = u * 8 + 2 * e2 + k;                  // position in plane order
+                    int src = pos;
+                    if (A_BF16) {                                        // RR_X3_ORDER_WIDE_BF16
+                        const int e = pos & 31, v = e >> 4, hh = (e >> 3) & 1, j = e & 7;
+                        src = (pos & ~31) + 16 * hh + 8 * v + j;
+                    }
+                    const float x = raw_q[qn * 384 + src];
+                    x1[k] = __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
+                    const float r1 = x - x1[k];
+                    x2[k] = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+                    x3[k] = r1 - x2[k];
+                }
+                pl[0][e2] = rr_pack_hi(x1[0], x1[1]);
+                pl[1][e2] = rr_pack_hi(x2[0], x2[1]);
+                pl[2][e2] = rr_pack_hi(x3[0], x3[1]);
+            }
+#pragma unroll
+            for (int p3 = 0; p3 < 3; ++p3) qs[(p3 * QN + qn) * RR_X3W_QSTRIDE + u] = pl[p3];
+        }
+    } else if (!(DBG & 128)) {
         for (int i = tid; i < 3 * QN * RR_X3_UNITS; i += THREADS)
             qs[(i / RR_X3_UNITS) * RR_X3W_QSTRIDE + (i % RR_X3_UNITS)] = planes[i];
     }
@@ -460,9 +490,8 @@ static int rr_x3w_fallback_t(rr_index* ix, const float* d_q, int nq, int pool, i
     G.qs = QN;
     unsigned short* planes = reinterpret_cast<unsigned short*>(ix->d_qplanes);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
-    rr_launch_split_queries(d_q, planes, QN, A_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL, st);
     hipLaunchKernelGGL((rr_scan_x3w<NQ2, A_BF16, true>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
-                       reinterpret_cast<const u32x4*>(planes), ix->d_sims, ix->d_gmax, ix->d_smax, flags, nq);
+                       reinterpret_cast<const u32x4*>(planes), ix->d_sims, ix->d_gmax, ix->d_smax, flags, nq, d_q);
     rr_launch_select(ix, G, nq, pool, d_rows, d_scores, st, flags);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
