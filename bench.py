@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: queries/sec of the hybrid search path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,9 +10,12 @@ pool=150, over a synthetic corpus of --docs products x 384-d fp32 unit vectors w
 corpus of ~40 tokens per document (vocabulary 200k, Zipf 1.07); queries arrive in batches of
 --batch.  The corpus is row-sharded across the N GPUs (strong scaling: the corpus is fixed, a
 GPU holds docs/N rows); one RCCL all-gather per batch merges the per-shard candidates.
-A "step" = one batch through K1 (dense scan + top-pool) -> K2 (BM25 at the pool) ->
-[all-gather] -> K3 (fusion + top-k), queries resident in HBM, top-k copied back to pinned host
-memory asynchronously.  value = batch * steps / time, max time over ranks.
+
+A "step" = one batch end to end (SURVEY 8d timing protocol): H2D of the query vectors and of the
+BM25 token ids (pinned host buffers) -> K1 (dense scan + top-pool) -> K2 (BM25 at the pool) ->
+[all-gather] -> K3 (fusion + top-k) -> D2H of rows / order / finals into pinned host memory.
+The corpus itself is resident in HBM.  value = batch * steps / wall time of the K steps between two
+barrier + synchronize fences, max over ranks; per-step HIP-event deltas give median / p10 / p90.
 
 The JSON line also carries `roofline` (the dense scan kernel, timed with HIP events around every
 launch on the stream it runs on) and, at N=1, `cpu_baseline` (the oracle = port of the
@@ -21,7 +24,6 @@ reference's numpy / rank_bm25-style CPU path, timed on the host cores on a bound
 import argparse
 import ctypes as C
 import json
-import math
 import os
 import sys
 import time
@@ -32,17 +34,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DIM = 384
-SEED = 1234
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
-F32_MATRIX_PEAK_TF = 157.3   # dense f32-input MFMA peak = f32 vector peak (MI355X_MICROARCH.md)
-N_BLOCKS = 8                 # the corpus is generated in 8 seeded blocks so any N in {1,2,4,8} sees the same data
+BF16_MFMA_PEAK_PF = 2.5      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--docs", type=int, default=10_000_000)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=100)
@@ -57,169 +57,144 @@ def parse():
     return ap.parse_args()
 
 
-def zipf_cdf(vocab, s=1.07):
-    w = 1.0 / np.power(np.arange(1, vocab + 1, dtype=np.float64), s)
-    return np.cumsum(w / w.sum())
-
-
-def gen_block(torch, dev, block, rows, vocab, doc_len, cdf_dev, want_bm25):
-    """One seeded corpus block on the device: unit rows, metadata, forward BM25 entries."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(SEED * 1000 + block)
-    x = torch.randn((rows, DIM), generator=g, device=dev, dtype=torch.float32)
-    n_rev = torch.clamp(torch.floor(torch.exp(torch.randn(rows, generator=g, device=dev, dtype=torch.float64)
-                                              * 1.2 + 2.5)), 1, 5000)
-    stars = torch.round(torch.clamp(torch.randn(rows, generator=g, device=dev, dtype=torch.float64) * 0.6 + 4.1,
-                                    1.0, 5.0) * 1000) / 1000
-    out = {"x": x, "n": n_rev, "stars": stars}
-    if want_bm25:
-        dl = torch.clamp(torch.poisson(torch.full((rows,), float(doc_len), device=dev), generator=g), min=1).long()
-        total = int(dl.sum().item())
-        u = torch.rand(total, generator=g, device=dev, dtype=torch.float64)
-        tok = torch.clamp(torch.searchsorted(cdf_dev, u), max=vocab - 1)
-        doc = torch.repeat_interleave(torch.arange(rows, device=dev), dl)
-        key, _ = torch.sort(doc * vocab + tok)
-        uniq, cnt = torch.unique_consecutive(key, return_counts=True)
-        out.update(doc_len=dl.int(), e_doc=(uniq // vocab), e_term=(uniq % vocab).int(), e_tf=cnt.int())
-    return out
-
-
-def build_shard(torch, dist, args, rank, world, dev):
-    from review_recommender_amd import _lib
-    from review_recommender_amd.bm25 import idf_with_floor
-    from review_recommender_amd.engine import HybridSearcher
-    from review_recommender_amd.index import ProductIndex
-    from review_recommender_amd.sharded import ShardedSearcher, shard_bounds
-
-    assert args.docs % N_BLOCKS == 0 and N_BLOCKS % world == 0, "docs %% 8 == 0 and gpus in {1,2,4,8}"
-    per_block = args.docs // N_BLOCKS
-    blocks = range(rank * N_BLOCKS // world, (rank + 1) * N_BLOCKS // world)
-    lo, hi = shard_bounds(args.docs, world, rank)
-    n_local = hi - lo
-    want_bm25 = not args.no_bm25
-    cdf_dev = torch.from_numpy(zipf_cdf(args.vocab)).to(dev) if want_bm25 else None
-
-    mat = torch.empty((n_local, DIM), device=dev, dtype=torch.float32)
-    n_rev = torch.empty(n_local, device=dev, dtype=torch.float64)
-    stars = torch.empty(n_local, device=dev, dtype=torch.float64)
-    parts = []
-    for j, b in enumerate(blocks):
-        blk = gen_block(torch, dev, b, per_block, args.vocab, args.doc_len, cdf_dev, want_bm25)
-        s = j * per_block
-        mat[s:s + per_block] = blk["x"]
-        n_rev[s:s + per_block] = blk["n"]
-        stars[s:s + per_block] = blk["stars"]
-        if want_bm25:
-            parts.append((blk["doc_len"], blk["e_doc"] + s, blk["e_term"], blk["e_tf"]))
-        del blk
-    if args.dtype == "bf16":
-        # normalise in fp32, round once to bf16 (nearest even): SURVEY section 8d
-        mat = (mat / torch.clamp(mat.norm(dim=1, keepdim=True), min=1e-12)).to(torch.bfloat16).contiguous()
-        index = ProductIndex(None, n_rows=n_local, dim=DIM, device=dev.index, row_offset=lo,
-                             device_ptr=mat.data_ptr(), keepalive=mat, dtype="bf16")
-    else:
-        index = ProductIndex(None, n_rows=n_local, dim=DIM, device=dev.index, row_offset=lo,
-                             device_ptr=mat.data_ptr(), keepalive=mat)
-        index.l2_normalize()                          # utils.py:40-44 on the device
-    index.set_meta(n_rev.cpu().numpy(), stars.cpu().numpy())
-
-    bm25 = None
-    keep = [mat]
-    if want_bm25:
-        doc_len = torch.cat([p[0] for p in parts])
-        e_doc = torch.cat([p[1] for p in parts])
-        e_term = torch.cat([p[2] for p in parts])
-        e_tf = torch.cat([p[3] for p in parts])
-        del parts
-        nnz = int(e_doc.numel())
-        doc_indptr = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
-        doc_indptr[1:] = torch.cumsum(torch.bincount(e_doc, minlength=n_local), 0)
-        # postings: entries sorted by (term, doc)
-        pkey, perm = torch.sort(e_term.long() * n_local + e_doc)
-        post_docs = (pkey % n_local).int()
-        post_tf = e_tf[perm].contiguous()
-        df_local = torch.bincount(e_term.long(), minlength=args.vocab)
-        post_indptr = torch.zeros(args.vocab + 1, dtype=torch.int64, device=dev)
-        post_indptr[1:] = torch.cumsum(df_local, 0)
-        del pkey, perm
-        # corpus-wide statistics (setup-time collectives; not on the query path)
-        df = df_local.clone()
-        tot_len = doc_len.long().sum().reshape(1)
-        if world > 1:
-            dist.all_reduce(df)
-            dist.all_reduce(tot_len)
-        avgdl = int(tot_len.item()) / args.docs
-        idf = torch.from_numpy(idf_with_floor(df.cpu().numpy(), args.docs)).to(dev)
-        e_term32, e_doc = e_term.contiguous(), None
-        h = C.c_void_p()
-        p = lambda t: C.c_void_p(t.data_ptr())
-        _lib.check(_lib.load().rr_bm25_create_dev(
-            dev.index, n_local, args.vocab, nnz, p(post_indptr), p(post_docs), p(post_tf), p(doc_indptr),
-            p(e_term32), p(e_tf), p(doc_len), p(idf), avgdl, 1.5, 0.75, lo, C.byref(h)), "rr_bm25_create_dev")
-
-        class _Dev:                                   # minimal BM25Index look-alike over adopted arrays
-            handle = h
-        bm25 = _Dev()
-        keep += [post_indptr, post_docs, post_tf, doc_indptr, e_term32, e_tf, doc_len, idf]
-        stats = dict(nnz=nnz, avgdl=avgdl, df=df.cpu().numpy())
-    else:
-        stats = dict(nnz=0, avgdl=0.0, df=None)
-    searcher = HybridSearcher(index, bm25)
-    sharded = ShardedSearcher(searcher, args.docs, rank, world)
-    sharded.force_payload = args.force_payload
-    return sharded, index, keep, stats, n_local
-
-
-def make_queries(torch, dev, args, stats, n_sets=4):
+def make_queries(torch, args, stats, n_sets=4):
+    """Host-side query sets: pinned (batch, 384) fp32 vectors + flattened BM25 token ids."""
     from review_recommender_amd import synth
     sets = []
     for i in range(n_sets):
-        q = torch.from_numpy(synth.unit_rows(args.batch, DIM, 4321 + i)).to(dev)
-        if args.no_bm25:
-            terms = None
-        else:
-            terms = synth.query_terms(args.batch, args.vocab, 99 + i, stats["df"])
+        q = torch.from_numpy(synth.unit_rows(args.batch, DIM, 4321 + i)).pin_memory()
+        terms = None
+        if not args.no_bm25:
+            lists = synth.query_terms(args.batch, args.vocab, 99 + i, stats["df"])
+            off = np.zeros(args.batch + 1, dtype=np.int32)
+            np.cumsum([len(t) for t in lists], out=off[1:])
+            terms = (np.concatenate(lists).astype(np.int32), off)
+            # realised postings per query (SURVEY 8d: "record the realised sum of df(t) per query")
+            stats["sum_df_per_query"] = float(np.mean([stats["df"][t].sum() for t in lists]))
         sets.append((q, terms))
     return sets
 
 
-def cpu_baseline(args, index_matrix_sample, stats, query_sets):
-    """The reference's CPU path (its numpy cosine search + rank_bm25-style scoring + the sku dict
-    of app/app_product_search.py:206-208), restated in oracle/, timed on this box's host cores on
-    a bounded sample and scaled linearly in the number of documents.  Reported, never the target."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(torch, args, shard, query_sets):
+    """The reference's CPU path restated in oracle/ (`kind: "port"`), timed on this box's host cores on
+    a bounded sample of the same workload (SURVEY 8d row "CPU baseline"):
+      dense    numpy matvec + argpartition + argsort (utils.py:114-122) on <= 1M rows, all BLAS threads and 1;
+      bm25     rank_bm25-style per-token Python loop over per-document dicts + the sku dict of
+               app/app_product_search.py:206-208 on 50k documents; vectorised CSR numpy on <= 1M documents;
+      pipeline the whole restated run_search at 10k products (BASELINE config 1) and at <= 1M.
+    `value` = the reference's own path (numpy dense on all cores + Python-loop BM25 + sku dict), every
+    part scaled linearly in documents to --docs.  Reported beside the GPU figure, never the target."""
+    import pandas as pd
+    from threadpoolctl import threadpool_limits
     from oracle.bm25 import BM25OkapiOracle
     from oracle.dense import cosine_similarity_search
-    V = index_matrix_sample
-    qs = query_sets[0][0].cpu().numpy()
-    cosine_similarity_search(qs[0], V, 150)                      # warm BLAS threads
-    t0 = time.perf_counter()
-    reps = 5
-    for i in range(reps):
-        cosine_similarity_search(qs[i % len(qs)], V, 150)
-    t_dense = (time.perf_counter() - t0) / reps * (args.docs / V.shape[0])
-    t_bm25, bm_docs = 0.0, 0
-    if not args.no_bm25:
-        bm_docs = 20_000
-        rng = np.random.default_rng(7)
-        cdf = zipf_cdf(args.vocab)
-        corpus = [np.minimum(np.searchsorted(cdf, rng.random(max(1, rng.poisson(args.doc_len)))),
-                             args.vocab - 1).tolist() for _ in range(bm_docs)]
-        bm = BM25OkapiOracle(corpus)
-        skus = [f"B{i:09d}" for i in range(bm_docs)]
-        terms = query_sets[0][1]
+    from oracle.pipeline import run_search_oracle
+    from review_recommender_amd import synth
+
+    n_s = min(shard.n_local, 1_000_000)
+    V = shard.matrix[:n_s].float().cpu().numpy()
+    qs = query_sets[0][0].numpy()
+    scale = args.docs / n_s
+    out = {}
+
+    def timed(fn, reps):
+        fn(0)
         t0 = time.perf_counter()
-        reps_b = 3
-        for i in range(reps_b):
-            scores = np.array(bm.get_scores(terms[i].tolist()), dtype=np.float32)
-            by_sku = {skus[j]: scores[j] for j in range(bm_docs)}    # app/app_product_search.py:207
-            _ = [by_sku.get(s, 0.0) for s in skus[:150]]
-        t_bm25 = (time.perf_counter() - t0) / reps_b * (args.docs / bm_docs)
-    qps = 1.0 / (t_dense + t_bm25)
+        for i in range(reps):
+            fn(i + 1)
+        return (time.perf_counter() - t0) / reps
+
+    t_dense_all = timed(lambda i: cosine_similarity_search(qs[i % len(qs)], V, 150), 5)
+    with threadpool_limits(limits=1):
+        t_dense_1 = timed(lambda i: cosine_similarity_search(qs[i % len(qs)], V, 150), 2)
+    out["dense_all_cores_ms"] = round(t_dense_all * scale * 1e3, 2)
+    out["dense_1_core_ms"] = round(t_dense_1 * scale * 1e3, 2)
+    t_loop = t_csr = 0.0
+    if not args.no_bm25:
+        a = shard.bm25_arrays
+        flat, off = query_sets[0][1]
+        tl = [flat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+        # (a) Python loop over per-document dicts, 50k documents (documents as token-id lists)
+        n_l = min(50_000, n_s)
+        ip = a["doc_indptr"][:n_l + 1].cpu().numpy()
+        dt = a["doc_terms"][:int(ip[-1])].cpu().numpy()
+        df_ = a["doc_tf"][:int(ip[-1])].cpu().numpy()
+        corpus = [np.repeat(dt[ip[d]:ip[d + 1]], df_[ip[d]:ip[d + 1]]).tolist() for d in range(n_l)]
+        bm = BM25OkapiOracle(corpus)
+        skus = synth.skus(n_l)
+
+        def loop(i):
+            scores = np.array(bm.get_scores(tl[i % len(tl)].tolist()), dtype=np.float32)
+            by_sku = {skus[j]: scores[j] for j in range(n_l)}                # app/app_product_search.py:207
+            return [by_sku.get(s, 0.0) for s in skus[:150]]
+        t_loop = timed(loop, 3) * (args.docs / n_l)
+        out["bm25_python_loop_ms"] = round(t_loop * 1e3, 1)
+        out["bm25_python_loop_docs"] = n_l
+        # (b) vectorised CSR numpy over the sample's postings (sorted on the GPU: setup, not timed)
+        csr = _csr_oracle(torch, a, n_s, args.vocab)
+        rows150 = np.arange(150)
+        t_csr = timed(lambda i: csr.get_scores(tl[i % len(tl)].tolist())[rows150].astype(np.float32), 5) * scale
+        out["bm25_csr_numpy_ms"] = round(t_csr * 1e3, 2)
+
+        # (c) the whole restated run_search (app flavour: sku dict over all documents) at 10k and at the sample
+        class _Ids:
+            def get_scores(self, toks):
+                return csr.get_scores([int(t[1:]) for t in toks])
+        n_rev, stars = synth.metadata(n_s, 2)
+        all_skus = synth.skus(n_s)
+        for n_p, reps in ((10_000, 5), (n_s, 2)):
+            meta = pd.DataFrame({"sku": all_skus[:n_p], "n_reviews": n_rev[:n_p], "avg_stars": stars[:n_p],
+                                 "agg_text": ""})
+            small = _csr_oracle(torch, a, n_p, args.vocab) if n_p < n_s else csr
+
+            class _B:
+                def get_scores(self, toks, _c=small):
+                    return _c.get_scores([int(t[1:]) for t in toks])
+
+            def full(i, _m=meta, _n=n_p):
+                q = " ".join(f"t{int(t)}" for t in tl[i % len(tl)])
+                return run_search_oracle(query=q, qvec=qs[i % len(qs)], meta=_m, V=V[:_n], bm25=_B(),
+                                         bm25_skus=all_skus[:_n], k=args.k, rerank_k=0, w_dense=0.5, w_bm25=0.5,
+                                         w_rerank=0.0, w_prior=0.0, w_best=0.0, prior_C=20.0, min_reviews=8,
+                                         gate_penalty=1.0)
+            out[f"run_search_{n_p}_products_ms"] = round(timed(full, reps) * 1e3, 1)
+    qps = 1.0 / (t_dense_all * scale + t_loop)
     return {"value": round(qps, 4), "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": (f"dense: numpy matvec+argpartition on {V.shape[0]} of {args.docs} rows x5 queries "
-                       f"(all BLAS threads); bm25: rank_bm25-style Python scoring + sku dict on {bm_docs} docs "
-                       f"x3 queries (1 thread); both scaled linearly to {args.docs} docs; "
-                       f"dense {t_dense * 1e3:.1f} ms + bm25 {t_bm25 * 1e3:.1f} ms per query")}
+            "cpu_model": _cpu_model(), "blas_threads": os.cpu_count(),
+            "sample": (f"reference-shaped path = numpy matvec+argpartition on {n_s} of {args.docs} rows (all BLAS "
+                       f"threads, x{scale:.0f}) + rank_bm25-style Python scoring + sku dict on "
+                       f"{out.get('bm25_python_loop_docs', 0)} docs (1 thread, scaled linearly); "
+                       "variants_ms are per query at --docs documents except run_search_*_products_ms "
+                       "(per query at that many products, unscaled)"),
+            "variants_ms": out}
+
+
+def _csr_oracle(torch, a, n_docs, vocab):
+    """BM25CsrOracle over the first n_docs documents of the shard's forward arrays (postings = the forward
+    entries sorted by (term, doc), on the GPU; corpus-wide idf / avgdl as the shard itself uses)."""
+    from oracle.bm25 import BM25CsrOracle
+    ip = a["doc_indptr"][:n_docs + 1]
+    nnz = int(ip[-1].item())
+    doc_of = torch.repeat_interleave(torch.arange(n_docs, device=ip.device), ip[1:] - ip[:-1])
+    terms = a["doc_terms"][:nnz].long()
+    key, perm = torch.sort(terms * n_docs + doc_of)
+    post_docs = (key % n_docs).int().cpu().numpy()
+    post_tf = a["doc_tf"][:nnz][perm].cpu().numpy()
+    pip = np.zeros(vocab + 1, dtype=np.int64)
+    np.cumsum(torch.bincount(terms, minlength=vocab).cpu().numpy(), out=pip[1:])
+    return BM25CsrOracle(pip, post_docs, post_tf, a["doc_len"][:n_docs].cpu().numpy(), a["idf"].cpu().numpy(),
+                         a["avgdl"])
 
 
 def main():
@@ -239,20 +214,27 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    from review_recommender_amd.device_corpus import build_device_shard
     from review_recommender_amd.engine import FusionWeights
-    sharded, index, keep, stats, n_local = build_shard(torch, dist, args, rank, world, dev)
-    qsets = make_queries(torch, dev, args, stats)
+    shard = build_device_shard(torch, dist, docs=args.docs, rank=rank, world=world, dev=dev, vocab=args.vocab,
+                               doc_len=args.doc_len, want_bm25=not args.no_bm25, dtype=args.dtype,
+                               force_payload=args.force_payload)
+    sharded, index, stats, n_local = shard.sharded, shard.index, shard.stats, shard.n_local
+    qsets = make_queries(torch, args, stats)
     w = FusionWeights(w_dense=0.5, w_bm25=0.0 if args.no_bm25 else 0.5, w_rerank=0.0, w_prior=0.0,
                       w_best=0.0, gate_penalty=1.0)
     pool = max(args.k, 150)
+    q_dev = [torch.empty((args.batch, DIM), dtype=torch.float32, device=dev) for _ in range(2)]
     pin_rows = torch.empty((args.batch, pool), dtype=torch.int64).pin_memory()
     pin_order = torch.empty((args.batch, args.k), dtype=torch.int32).pin_memory()
     pin_final = torch.empty((args.batch, pool), dtype=torch.float64).pin_memory()
 
     def step(i):
-        q, terms = qsets[i % len(qsets)]
+        q_pin, terms = qsets[i % len(qsets)]
+        q = q_dev[i % 2]
+        q.copy_(q_pin, non_blocking=True)                        # H2D: query vectors (token ids: inside search)
         rows, cols, order = sharded.search_batch_dev(q, terms, args.k, w)
-        pin_rows.copy_(rows, non_blocking=True)
+        pin_rows.copy_(rows, non_blocking=True)                  # D2H: the answer
         pin_order.copy_(order, non_blocking=True)
         pin_final.copy_(cols[:, 7, :], non_blocking=True)
 
@@ -265,10 +247,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    index_scan = _scan_stats(index)           # drain warm-up launches
+    _scan_stats(index)                         # drain warm-up launches
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         step(i)
+        marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -276,9 +261,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     total_ms, launches = _scan_stats(index)
+    info = _scan_info(index)
+    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
 
     # the HBM-bound end of the path: one query per matrix read (rr_scan_f32<6,1>), same shard
-    q1 = qsets[0][0][:1].contiguous()
+    q1 = q_dev[0][:1].contiguous()
     for _ in range(2):
         sharded.s.dense_pool(q1, pool)
     torch.cuda.synchronize()
@@ -287,63 +274,40 @@ def main():
         sharded.s.dense_pool(q1, pool)
     torch.cuda.synchronize()
     ms1, n1 = _scan_stats(index)
-    gbs1 = n_local * DIM * (2 if args.dtype == "bf16" else 4) / (ms1 / max(n1, 1) * 1e-3) / 1e9
+    esz = 2 if args.dtype == "bf16" else 4
+    bytes_per_launch = n_local * DIM * esz            # algorithmic: the shard's matrix, read once per launch
+    gbs1 = bytes_per_launch / (ms1 / max(n1, 1) * 1e-3) / 1e9
     single = {"bound": "hbm", "achieved": round(gbs1, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-              "frac": round(gbs1 / HBM_PEAK_GBS, 4), "kernel": "rr_scan_bf16<1>" if args.dtype == "bf16" else "rr_scan_f32<6,1>", "launches": int(n1),
-              "avg_launch_ms": round(ms1 / max(n1, 1), 5),
-              "bytes_per_launch": n_local * DIM * (2 if args.dtype == "bf16" else 4)}
+              "frac": round(gbs1 / HBM_PEAK_GBS, 4),
+              "kernel": "rr_scan_bf16<1>" if args.dtype == "bf16" else "rr_scan_f32<6,1>", "launches": int(n1),
+              "avg_launch_ms": round(ms1 / max(n1, 1), 5), "bytes_per_launch": bytes_per_launch}
 
     if rank == 0:
-        # HBM traffic per launch from the PMC passes kept in profiles/ (FETCH_SIZE x2 on gfx950 +
-        # WRITE_SIZE, MI355X_MICROARCH.md), measured on this kernel at this many queries per launch
-        # on 10M rows; the same bytes-per-row ratio is applied to this run's rows.  null when no
-        # PMC summary for this launch shape is present.
-        exact = bool(os.environ.get("RR_SCAN_EXACT"))
-        qpl = min(args.batch, 64 if exact else 128) if args.batch > 4 else args.batch   # queries sharing one matrix read
-        traffic = None
-        chain_tag = ("chain_" if os.environ.get("RR_SCAN_F32_CHAIN") else "exact_" if exact else "") if qpl > 4 else ""
-        pmc = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_scan_{chain_tag}b{qpl}_10M.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                m = json.load(f)
-            if args.dtype == "f32":
-                traffic = int(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"] * n_local * DIM * 4)
-        esz = 2 if args.dtype == "bf16" else 4
-        bytes_per_launch = n_local * DIM * esz    # algorithmic: the shard's matrix, read once per launch
         avg_ms = total_ms / max(launches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-        chain = bool(os.environ.get("RR_SCAN_F32_CHAIN"))
-        if qpl > 4 and not chain:
-            # 5..128 queries per read: bf16 filter scan on the matrix cores (rr_dense_flt.hip: one MFMA term per
-            # dim, candidates rescored exactly) -- or, with RR_SCAN_EXACT=1, the split-operand scans (6 terms for
-            # fp32 storage, 3 for bf16; rr_dense_x3.hip up to 16 queries, rr_dense_x3w.hip up to 64).  Both the HBM
-            # fraction and the matrix-core fraction are reported; the larger one names the bound.
-            terms = 1 if not exact else (3 if args.dtype == "bf16" else 6)
-            pf = terms * 2.0 * n_local * DIM * qpl / (avg_ms * 1e-3) / 1e15 if launches else 0.0
-            hbm_frac, mfma_frac = achieved / HBM_PEAK_GBS, pf / 2.5
-            roof = {"bound": "hbm" if hbm_frac >= mfma_frac else "mfma", "achieved": round(achieved, 2),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic,
-                    "kernel": (f"rr_scan_flt<{1 if qpl <= 32 else 2 if qpl <= 64 else 4},{args.dtype}>" if not exact else
-                               f"rr_scan_mfma_x3<1,{args.dtype}>" if qpl <= 16 else
-                               f"rr_scan_x3w<{1 if qpl <= 32 else 2},{args.dtype}>"),
-                    "matrix_core_pflops": round(pf, 4), "matrix_core_frac_of_2.5PF": round(mfma_frac, 4)}
-            if mfma_frac > hbm_frac:
-                roof.update({"achieved": round(pf * 1e3, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                             "frac": round(mfma_frac, 4)})
-        elif qpl > 32:
-            # RR_SCAN_F32_CHAIN: f32-input MFMA kernels; > 32 queries per read is past the f32 ridge
-            flops = 2.0 * n_local * DIM * qpl
-            tf = flops / (avg_ms * 1e-3) / 1e12 if launches else 0.0
-            roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(tf / F32_MATRIX_PEAK_TF, 4), "traffic": traffic,
-                    "kernel": "rr_scan_mfma_bf16<4>" if args.dtype == "bf16" else "rr_scan_mfma_f32<4>",
-                    "hbm_read_gbs": round(achieved, 2)}
-        else:
-            roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "kernel": ("rr_scan_" if qpl <= 4 else "rr_scan_mfma_") + args.dtype}
-        roof.update({"launches": int(launches), "avg_launch_ms": round(avg_ms, 5),
-                     "bytes_per_launch": bytes_per_launch, "queries_per_launch": qpl})
+        qpl, terms_per_dim = info["queries_per_launch"], info["mfma_terms"]
+        # HBM traffic per launch from the PMC passes kept in profiles/ (FETCH_SIZE / WRITE_SIZE collected and
+        # corrected as MI355X_MICROARCH.md prescribes), for this kernel at this many queries per launch on 10M
+        # rows; the same bytes-per-row ratio is applied to this run's rows.  null without such a summary.
+        traffic = None
+        for tag in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_scan_b{qpl}_10M.json")
+            if os.path.exists(pmc) and args.dtype == "f32":
+                with open(pmc) as f:
+                    m = json.load(f)
+                traffic = int(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"] * bytes_per_launch)
+                break
+        pf = terms_per_dim * 2.0 * n_local * DIM * qpl / (avg_ms * 1e-3) / 1e15 if launches else 0.0
+        hbm_frac, mfma_frac = achieved / HBM_PEAK_GBS, pf / BF16_MFMA_PEAK_PF
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(hbm_frac, 4), "traffic": traffic, "kernel": info["kernel"],
+                "launches": int(launches), "avg_launch_ms": round(avg_ms, 5), "bytes_per_launch": bytes_per_launch,
+                "queries_per_launch": qpl, "launches_per_step": round(launches / max(args.steps, 1), 3)}
+        if terms_per_dim:
+            roof.update({"matrix_core_pflops": round(pf, 4), "matrix_core_frac_of_2.5PF": round(mfma_frac, 4)})
+            if mfma_frac > hbm_frac:      # both fractions are printed; the larger one names the bound
+                roof.update({"bound": "mfma", "achieved": round(pf * 1e3, 2), "peak": BF16_MFMA_PEAK_PF * 1e3,
+                             "unit": "TFLOP/s", "frac": round(mfma_frac, 4), "hbm_read_gbs": round(achieved, 2)})
         out = {
             "metric": "queries/sec at top-k=100 (hybrid alpha=0.5)" if not args.no_bm25
                       else "queries/sec at top-k=100 (dense only)",
@@ -352,10 +316,16 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "storage": args.dtype,
+            "ms_per_step_median": round(float(np.median(per_step)), 4),
+            "ms_per_step_p10": round(float(np.percentile(per_step, 10)), 4),
+            "ms_per_step_p90": round(float(np.percentile(per_step, 90)), 4),
+            "timed_region": "H2D queries + token ids -> K1 -> K2 -> [all-gather] -> K3 -> D2H rows/order/finals",
+            "scan_ms_per_step": round(total_ms / max(args.steps, 1), 4),
             "config": {"workload": (f"{'hybrid BM25+dense alpha=0.5' if not args.no_bm25 else 'dense-only cosine'} "
                                     f"top-k={args.k} pool={pool}, {args.docs} products x {DIM} {'bf16-stored' if args.dtype == 'bf16' else 'fp32'}"
                                     + (f", BM25 ~{args.doc_len} tokens/doc vocab {args.vocab} "
-                                       f"({stats['nnz']} postings on rank 0)" if not args.no_bm25 else "")
+                                       f"({stats['nnz']} postings on rank 0, {stats.get('sum_df_per_query', 0):.0f} "
+                                       f"postings per query)" if not args.no_bm25 else "")
                                     + f", batches of {args.batch} queries"),
                        "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k,
                        "pool": pool, "parallelism": f"row-shard x{world} + 1 all-gather"},
@@ -364,9 +334,7 @@ def main():
             "roofline_single_query": single,
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample_rows = min(n_local, 1_000_000)
-            sample = keep[0][:sample_rows].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(args, sample, stats, qsets)
+            out["cpu_baseline"] = cpu_baseline(torch, args, shard, qsets)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -378,6 +346,21 @@ def _scan_stats(index):
     tot, n = C.c_double(), C.c_int64()
     _lib.check(_lib.load().rr_index_scan_stats(index.handle, C.byref(tot), C.byref(n)), "rr_index_scan_stats")
     return tot.value, n.value
+
+
+_KERNELS = {1: "rr_scan_f32<6,NB>", 2: "rr_scan_bf16<NB>", 3: "rr_scan_mfma_x3<1>", 4: "rr_scan_x3w<NQT>",
+            5: "rr_scan_flt<NQ2>", 6: "rr_scan_mfma_f32<NQT>", 7: "rr_scan_mfma_bf16"}
+
+
+def _scan_info(index):
+    """Which scan kernel the last batched launch used (rr_index_last_scan_info)."""
+    from review_recommender_amd import _lib
+    out = (C.c_int32 * 8)()
+    _lib.check(_lib.load().rr_index_last_scan_info(index.handle, out), "rr_index_last_scan_info")
+    kid, variant, qpl, terms = out[0], out[1], out[2], out[3]
+    name = _KERNELS.get(kid, "unknown").replace("NQ2", str(variant)).replace("NQT", str(variant)).replace("NB", str(variant))
+    return {"kernel": f"{name},{'bf16' if index.dtype == 'bf16' else 'f32'}", "queries_per_launch": int(qpl),
+            "mfma_terms": int(terms)}
 
 
 if __name__ == "__main__":

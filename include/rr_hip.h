@@ -42,7 +42,7 @@ extern "C" {
 
 #define RR_MAX_POOL   2048   /* upper bound for pool / k */
 #define RR_MAX_BATCH  1024
-#define RR_MAX_QTERMS   64   /* query tokens per query kept by the BM25 kernels */
+#define RR_MAX_QTERMS   64   /* query tokens the BM25 candidate kernel stages per pass (longer queries take several passes) */
 
 typedef struct rr_index rr_index;   /* dense matrix + per-row metadata of one shard */
 typedef struct rr_bm25  rr_bm25;    /* BM25 postings (CSR by term) + forward CSR by doc */
@@ -96,6 +96,11 @@ int rr_index_last_scan_ms(rr_index* ix, float* out_ms);
 /* Every scan launch is bracketed by a HIP event pair on its stream (ring of 512).
  * Drains the pairs recorded since the last call: total ms and launch count. */
 int rr_index_scan_stats(rr_index* ix, double* out_total_ms, int64_t* out_launches);
+/* Which scan kernel the last scan launch on this handle ran: out8[0] = 1 rr_scan_f32, 2 rr_scan_bf16,
+ * 3 rr_scan_mfma_x3, 4 rr_scan_x3w, 5 rr_scan_flt, 6 rr_scan_mfma_f32, 7 rr_scan_mfma_bf16; [1] = its template
+ * variant (query tiles / query slots); [2] = queries in that launch; [3] = bf16 MFMA terms per dimension
+ * (0: not a bf16 matrix-core kernel).  bench.py names the roofline kernel from this. */
+int rr_index_last_scan_info(rr_index* ix, int32_t* out8);
 /* Path taken by the last top-pool selection for its first query: out16[0] = 2: M-tile maxima + rescoring
  * (the batched paths), 1: stored scores through the LDS-resident 3-level selection, 0: generic radix
  * fallback; [1..3] = groups opened, (M-)tiles opened, candidate rows; [4..] = shader-clock cycles of the
@@ -163,7 +168,8 @@ typedef struct rr_fuse_params {
     int32_t pool;            /* pool size to cut the candidates to before fusing */
     int32_t cand_per_rank;   /* 0: candidate arrays are [query][n_candidates]; else the arrays are
                                 gathered shard payloads [rank][query][cand_per_rank] */
-    int32_t _pad;
+    int32_t bm25_f64;        /* 1: the _bm25 column is the CLI's float64 zeros (`cand["_bm25"] = 0.0`, app/test.py:252:
+                                no BM25 artefact): the blend is float64 from its second term on; d_bm25 must be NULL */
     int64_t cand_rank_stride_bytes; /* distance between two ranks' payload blocks */
 } rr_fuse_params;
 
@@ -215,6 +221,13 @@ int rr_reviews_destroy(rr_reviews* rv);
 int rr_reviews_best_dev(rr_reviews* rv, const float* d_queries, int32_t n_queries,
                         const int64_t* d_rows, int32_t pool, int64_t row_offset, int32_t max_review_id,
                         float* d_best_score, int32_t* d_best_id, void* stream);
+
+/* The same for a whole batch with the reference's `iloc[:max_rows]` cut (app/app_product_search.py:342-345,
+ * app/test.py:200-203) evaluated per query ON THE DEVICE: among the reviews of query q's candidates, in file
+ * (= review id) order, only the first max_rows are scored; max_rows <= 0 scores none.  No host round trip. */
+int rr_reviews_best_cut_dev(rr_reviews* rv, const float* d_queries, int32_t n_queries,
+                            const int64_t* d_rows, int32_t pool, int64_t row_offset, int64_t max_rows,
+                            float* d_best_score, int32_t* d_best_id, void* stream);
 
 /* Development aid (tools/x3w_ablate.py): times ablated variants of the 64-query fp32 batched scan
  * (bit 0: no operand split, bit 1: no B-fragment reads, bit 2: no MFMA, bit 3: no lane swap).

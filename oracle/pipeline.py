@@ -183,10 +183,11 @@ def run_search_oracle(
     return out, snips, dbg, cand
 
 
-def cli_rows(frame: pd.DataFrame) -> List[Dict]:
+def cli_rows(frame: pd.DataFrame, snippets: Optional[Dict] = None) -> List[Dict]:
     """app/test.py:312-328: the CLI's JSON row schema (4-dp rounding)."""
     rows = []
     for _, row in frame.iterrows():
+        snip = snippets.get(str(row["sku"])) if snippets else None
         rows.append({
             "sku": str(row["sku"]),
             "score": round(float(row["_final"]), 4),
@@ -199,7 +200,7 @@ def cli_rows(frame: pd.DataFrame) -> List[Dict]:
                              if pd.notna(row.get("n_reviews", np.nan)) else 0),
             "avg_stars": round(float(row.get("avg_stars", np.nan)), 2)
             if pd.notna(row.get("avg_stars", np.nan)) else None,
-            "snippet_stars": None,
-            "snippet": None,
+            "snippet_stars": float(snip["stars"]) if snip and snip.get("stars") is not None else None,
+            "snippet": snip["text"] if snip else None,
         })
     return rows

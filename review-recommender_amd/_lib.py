@@ -18,7 +18,7 @@ class FuseParams(C.Structure):
                 ("min_reviews", c_i32), ("trust_sat", c_i32), ("apply_trust", c_i32),
                 ("rerank_active", c_i32), ("rerank_k", c_i32), ("k", c_i32),
                 ("n_candidates", c_i32), ("pool", c_i32), ("cand_per_rank", c_i32),
-                ("_pad", c_i32), ("cand_rank_stride_bytes", c_i64)]
+                ("bm25_f64", c_i32), ("cand_rank_stride_bytes", c_i64)]
 
 
 # name -> (restype, argtypes); every symbol include/rr_hip.h declares
@@ -38,6 +38,7 @@ PROTOTYPES = {
     "rr_dense_topk_dev": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rr_index_last_scan_ms": (C.c_int, [c_vp, P(c_f32)]),
     "rr_index_scan_stats": (C.c_int, [c_vp, P(c_f64), P(c_i64)]),
+    "rr_index_last_scan_info": (C.c_int, [c_vp, P(c_i32)]),
     "rr_index_select_trace": (C.c_int, [c_vp, P(c_i32)]),
     "rr_index_set_scan_mode": (C.c_int, [c_vp, c_i32]),
     "rr_debug_scan_x3w": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
@@ -56,6 +57,7 @@ PROTOTYPES = {
     "rr_reviews_create": (C.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_f32, P(c_vp)]),
     "rr_reviews_destroy": (C.c_int, [c_vp]),
     "rr_reviews_best_dev": (C.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "rr_reviews_best_cut_dev": (C.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "rr_index_stream": (C.c_int, [c_vp, P(c_vp)]),
     "rr_index_synchronize": (C.c_int, [c_vp]),
 }

@@ -27,6 +27,7 @@ from . import text
 EMB_FILE = "product_emb.npy"
 META_FILE = "product_emb_meta.parquet"
 BM25_FILE = "product_bm25.pkl"
+REVIEWS_FILE = "reviews_with_embeddings.parquet"   # sku, text, stars, embedding (app/test.py:26,181-199)
 REQUIRED_COLUMNS = ("sku", "agg_text")          # app/test.py:138-139
 AUDIT_COLUMNS = ("sku", "n_reviews", "avg_stars", "agg_text")   # test.py:175
 
@@ -88,3 +89,30 @@ def load_artifacts(data_dir, strict: bool = False, mmap: bool = True
         if len(blob["skus"]) != len(blob["corpus"]):
             raise ArtifactError(f"{BM25_FILE}: {len(blob['skus'])} skus vs {len(blob['corpus'])} documents")
     return meta.reset_index(drop=True), emb, blob
+
+
+def load_reviews(data_dir) -> Optional[Tuple[pd.DataFrame, np.ndarray]]:
+    """(review table with sku / text / stars, (n_reviews, dim) float32 embeddings) from
+    reviews_with_embeddings.parquet, or None when the file is absent (the reference then skips
+    snippets: app/test.py:186, app/app_product_search.py:285)."""
+    f = pathlib.Path(data_dir) / REVIEWS_FILE
+    if not f.exists():
+        return None
+    df = pd.read_parquet(f)
+    if "sku" not in df.columns or "embedding" not in df.columns:
+        return None                                   # app/test.py:190-192: warn and skip
+    emb = np.stack(df["embedding"].values).astype(np.float32) if len(df) else np.zeros((0, 1), np.float32)
+    if len(df) == 0:
+        return None
+    return df.drop(columns=["embedding"]).reset_index(drop=True), emb
+
+
+def save_reviews(data_dir, reviews: pd.DataFrame, embeddings: np.ndarray) -> pathlib.Path:
+    """Writes reviews_with_embeddings.parquet in the reference's layout
+    (nlp/11_build_product_embeddings.py:95-169: one list-valued `embedding` column)."""
+    d = pathlib.Path(data_dir)
+    d.mkdir(parents=True, exist_ok=True)
+    out = reviews.copy()
+    out["embedding"] = [np.asarray(e, dtype=np.float32) for e in embeddings]
+    out.to_parquet(d / REVIEWS_FILE, index=False)
+    return d / REVIEWS_FILE

@@ -1,6 +1,15 @@
-"""Builds librr_hip.so (hand-written HIP for gfx950) in-tree with hipcc."""
+"""Builds librr_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+Every source is compiled to its own object (in parallel) and the objects are linked into one shared
+library.  What decides whether anything is rebuilt is CONTENT, not mtime: the sha256 of a source, of
+every header and of the flags is kept beside its object, and the digest of all of them beside the
+library (`librr_hip.so.buildid`), so a stale library cannot hide behind a fresh timestamp and a fresh
+checkout with a prebuilt library (the GPU box) does not rebuild.
+"""
 from __future__ import annotations
 
+import concurrent.futures as cf
+import hashlib
 import os
 import pathlib
 import shutil
@@ -8,12 +17,14 @@ import subprocess
 
 PKG_DIR = pathlib.Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
+OBJ_DIR = PKG_DIR / "build"
 LIB_PATH = PKG_DIR / "librr_hip.so"
-SOURCES = ["rr_api.hip", "rr_dense.hip", "rr_dense_bf16.hip", "rr_dense_x3.hip", "rr_dense_x3w.hip", "rr_dense_flt.hip", "rr_bm25.hip", "rr_fuse.hip", "rr_reviews.hip"]
+BUILD_ID = PKG_DIR / "librr_hip.so.buildid"
+SOURCES = ["rr_api.hip", "rr_dense.hip", "rr_dense_bf16.hip", "rr_dense_x3.hip", "rr_dense_x3w.hip",
+           "rr_dense_flt.hip", "rr_bm25.hip", "rr_fuse.hip", "rr_reviews.hip"]
 # -ffp-contract=off: the BM25 and fusion kernels reproduce numpy's one-rounding-per-
 # operation arithmetic; fused multiply-adds are written out (__builtin_fmaf) where wanted.
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-         "-ffp-contract=off", "-Wno-unused-value"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
 
 
 def hipcc_path() -> str:
@@ -23,24 +34,65 @@ def hipcc_path() -> str:
     return exe
 
 
+def _headers():
+    return sorted(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "rr_hip.h"]
+
+
+def _digest(paths, extra: str = "") -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()
+
+
+def _source_digest(src: str) -> str:
+    return _digest([CSRC / src] + _headers(), " ".join(FLAGS))
+
+
+def library_digest() -> str:
+    return _digest([CSRC / s for s in SOURCES] + _headers(), " ".join(FLAGS))
+
+
 def needs_build() -> bool:
-    if not LIB_PATH.exists():
+    if not LIB_PATH.exists() or not BUILD_ID.exists():
         return True
-    built = LIB_PATH.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "rr_common.h", CSRC / "rr_dense.h", CSRC / "rr_x3.h",
-                                          PKG_DIR.parent / "include" / "rr_hip.h"]
-    return any(d.stat().st_mtime > built for d in deps)
+    return BUILD_ID.read_text().strip() != library_digest()
 
 
-def build_library(force: bool = False, verbose: bool = False) -> pathlib.Path:
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = [hipcc_path(), *FLAGS, *[str(CSRC / s) for s in SOURCES], "-o", str(LIB_PATH)]
+def _compile_one(src: str, verbose: bool) -> pathlib.Path:
+    obj = OBJ_DIR / (src + ".o")
+    tag = OBJ_DIR / (src + ".sha256")
+    want = _source_digest(src)
+    if obj.exists() and tag.exists() and tag.read_text().strip() == want:
+        return obj
+    cmd = [hipcc_path(), *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+        raise RuntimeError(f"hipcc failed on {src}:\n" + proc.stdout + proc.stderr)
+    tag.write_text(want)
+    return obj
+
+
+def build_library(force: bool = False, verbose: bool = False, jobs: int = 0) -> pathlib.Path:
+    if not force and not needs_build():
+        return LIB_PATH
+    OBJ_DIR.mkdir(exist_ok=True)
+    if force:
+        for f in OBJ_DIR.glob("*.sha256"):
+            f.unlink()
+    jobs = jobs or min(len(SOURCES), max(1, (os.cpu_count() or 2) - 1), 8)
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(lambda s: _compile_one(s, verbose), SOURCES))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB_PATH)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + proc.stdout + proc.stderr)
+    BUILD_ID.write_text(library_digest())
     return LIB_PATH
 
 

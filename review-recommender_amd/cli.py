@@ -30,8 +30,8 @@ def parse_args(argv=None):
     ap.add_argument("-q", "--query", required=True, help="User query")
     ap.add_argument("-k", "--k", type=int, default=10, help="How many results to show")
     ap.add_argument("--rerank_k", type=int, default=50, help="Cross-encoder rerank pool size (0 to disable)")
-    ap.add_argument("--no-snippets", action="store_true", help="accepted for compatibility; snippets are not scored")
-    ap.add_argument("--max-reviews-scan", type=int, default=1_000_000, help="accepted for compatibility")
+    ap.add_argument("--no-snippets", action="store_true", help="Disable review snippets (faster)")
+    ap.add_argument("--max-reviews-scan", type=int, default=1_000_000, help="Max reviews to load for snippets")
     ap.add_argument("--w-dense", type=float, default=0.55)
     ap.add_argument("--w-bm25", type=float, default=0.15)
     ap.add_argument("--w-rerank", type=float, default=0.15)
@@ -75,14 +75,17 @@ def main(argv=None) -> int:
                                              device=args.device)
     except ArtifactError as e:
         raise SystemExit(f"[ERR] {e}")
-    frame, _, _ = engine.run_search(args.query, args.k, args.rerank_k, args.w_dense, args.w_bm25, args.w_rerank,
-                                    args.w_prior, args.w_best, args.prior_C, False, 0, 8, args.gate_penalty,
-                                    qvec=qvec)
-    rows = cli_rows(frame)
+    # snippets are scored whenever the review file exists and --no-snippets is absent (app/test.py:271-276)
+    frame, snips, _ = engine.run_search(args.query, args.k, args.rerank_k, args.w_dense, args.w_bm25, args.w_rerank,
+                                        args.w_prior, args.w_best, args.prior_C, not args.no_snippets,
+                                        args.max_reviews_scan, 8, args.gate_penalty, qvec=qvec)
+    rows = cli_rows(frame, snips)
     print("\nTop results:")
     for i, r in enumerate(rows, 1):
         print(f"[{i}] {r['sku']}  score={r['score']}  (dense={r['dense']} bm25={r['bm25']} rerank={r['rerank']} "
               f"prior={r['prior']} best={r['bestrev']})  reviews={r['n_reviews']} avg={r['avg_stars']}")
+        if r["snippet"]:
+            print("    ", r["snippet"])                        # app/test.py:335-336
     if args.json_out:
         pathlib.Path(args.json_out).parent.mkdir(parents=True, exist_ok=True)
         with open(args.json_out, "w") as f:

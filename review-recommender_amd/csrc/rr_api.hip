@@ -57,6 +57,7 @@ extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim
     hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ix->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ix->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming);
     for (int i = 0; i < rr_index::kRing && e == hipSuccess; ++i) {
         e = hipEventCreate(&ix->ring0[i]);
         if (e == hipSuccess) e = hipEventCreate(&ix->ring1[i]);
@@ -124,8 +125,8 @@ extern "C" int rr_index_upload_rows_f32(rr_index* ix, int64_t first_row, int64_t
     RR_REQUIRE(ix->owns_matrix || !ix->d_matrix, "rr_index_upload_rows_f32: matrix is caller-owned");
     int rc = rr_alloc_matrix(ix);
     if (rc || n_rows == 0) return rc;
+    ix->norm_bound = -1.f;   // any write to the matrix (either storage dtype) invalidates the cached row-norm bound
     if (ix->dtype == RR_DTYPE_F32) {
-        ix->norm_bound = -1.f;
         char* dst = (char*)ix->d_matrix + (size_t)first_row * ix->dim_pad * 4;
         RR_HIP_TRY(hipMemcpy2DAsync(dst, 4 * (size_t)ix->dim_pad, h_rows, 4 * (size_t)ix->dim, 4 * (size_t)ix->dim,
                                     (size_t)n_rows, hipMemcpyHostToDevice, ix->stream));
@@ -188,6 +189,7 @@ extern "C" int rr_index_destroy(rr_index* ix) {
     hipFree(ix->d_rows_out); hipFree(ix->d_scores_out);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);
+    if (ix->ev_done) hipEventDestroy(ix->ev_done);
     for (int i = 0; i < rr_index::kRing; ++i) {
         if (ix->ring0[i]) hipEventDestroy(ix->ring0[i]);
         if (ix->ring1[i]) hipEventDestroy(ix->ring1[i]);

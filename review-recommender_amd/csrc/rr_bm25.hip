@@ -98,36 +98,40 @@ __global__ __launch_bounds__(256) void rr_bm25_at(rr_bm25_view v, const int32_t*
     const int q = blockIdx.y;
     const int c0 = blockIdx.x * RR_AT_CANDS;
     const int t0 = term_off[q];
-    int nt = term_off[q + 1] - t0;
-    if (nt > RR_MAX_QTERMS) nt = RR_MAX_QTERMS;  // the host wrapper rejects longer queries
+    const int nt = term_off[q + 1] - t0;
     const int nc = pool - c0 < RR_AT_CANDS ? pool - c0 : RR_AT_CANDS;
+    double sum = 0.0;                                 // candidate tid's running score (threads < nc)
 
-    for (int i = tid; i < nc * nt; i += 256) {
-        const int c = i / nt, j = i % nt;
-        const int64_t d = rows[(int64_t)q * pool + c0 + c] - v.row_offset;
-        const int32_t t = term_ids[t0 + j];
-        double val = 0.0;
-        if (d >= 0 && d < v.n_docs && t >= 0 && t < v.n_terms) {
-            int tf = 0;
-            if (MODE == 0) {
-                const int64_t s = v.doc_indptr[d], e = v.doc_indptr[d + 1];
-                const int64_t p = rr_lower_bound(v.doc_terms, s, e, t);
-                if (p < e && v.doc_terms[p] == t) tf = v.doc_tf[p];
-            } else {
-                const int64_t s = v.post_indptr[t], e = v.post_indptr[t + 1];
-                const int64_t p = rr_lower_bound(v.post_docs, s, e, (int32_t)d);
-                if (p < e && v.post_docs[p] == (int32_t)d) tf = v.post_tf[p];
+    // tokens in chunks of RR_MAX_QTERMS: get_scores has no token limit (a pasted paragraph is a legal query);
+    // the running sum keeps the additions in token order across chunks
+    for (int jb = 0; jb < nt; jb += RR_MAX_QTERMS) {
+        const int nj = nt - jb < RR_MAX_QTERMS ? nt - jb : RR_MAX_QTERMS;
+        for (int i = tid; i < nc * nj; i += 256) {
+            const int c = i / nj, j = i % nj;
+            const int64_t d = rows[(int64_t)q * pool + c0 + c] - v.row_offset;
+            const int32_t t = term_ids[t0 + jb + j];
+            double val = 0.0;
+            if (d >= 0 && d < v.n_docs && t >= 0 && t < v.n_terms) {
+                int tf = 0;
+                if (MODE == 0) {
+                    const int64_t s = v.doc_indptr[d], e = v.doc_indptr[d + 1];
+                    const int64_t p = rr_lower_bound(v.doc_terms, s, e, t);
+                    if (p < e && v.doc_terms[p] == t) tf = v.doc_tf[p];
+                } else {
+                    const int64_t s = v.post_indptr[t], e = v.post_indptr[t + 1];
+                    const int64_t p = rr_lower_bound(v.post_docs, s, e, (int32_t)d);
+                    if (p < e && v.post_docs[p] == (int32_t)d) tf = v.post_tf[p];
+                }
+                if (tf > 0) val = rr_bm25_term(v.idf[t], tf, v.doc_len[d], v.avgdl, v.k1, v.b);
             }
-            if (tf > 0) val = rr_bm25_term(v.idf[t], tf, v.doc_len[d], v.avgdl, v.k1, v.b);
+            contrib[c][j] = val;
         }
-        contrib[c][j] = val;
+        __syncthreads();
+        if (tid < nc)
+            for (int j = 0; j < nj; ++j) sum += contrib[tid][j];   // token order, like get_scores
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid < nc) {
-        double s = 0.0;
-        for (int j = 0; j < nt; ++j) s += contrib[tid][j];   // token order, like get_scores
-        out[(int64_t)q * pool + c0 + tid] = (float)s;        // np.array(..., dtype=np.float32)
-    }
+    if (tid < nc) out[(int64_t)q * pool + c0 + tid] = (float)sum;  // np.array(..., dtype=np.float32)
 }
 
 // ------------------------------------------------------------------ host side
@@ -303,9 +307,7 @@ extern "C" int rr_bm25_scores_at(rr_bm25* bm, const int32_t* h_term_ids, const i
     const int total_terms = h_term_off[n_queries];
     RR_REQUIRE(total_terms >= 0 && (total_terms == 0 || h_term_ids), "rr_bm25_scores_at: bad term arrays");
     for (int q = 0; q < n_queries; ++q)
-        RR_REQUIRE(h_term_off[q + 1] - h_term_off[q] >= 0 && h_term_off[q + 1] - h_term_off[q] <= RR_MAX_QTERMS,
-                   "rr_bm25_scores_at: query %d has %d tokens (limit %d)", q,
-                   h_term_off[q + 1] - h_term_off[q], RR_MAX_QTERMS);
+        RR_REQUIRE(h_term_off[q + 1] - h_term_off[q] >= 0, "rr_bm25_scores_at: term offsets must not decrease (query %d)", q);
     std::lock_guard<std::mutex> lk(bm->mu);
     RR_HIP_TRY(hipSetDevice(bm->device));
     int32_t *d_ids = nullptr, *d_off = nullptr;

@@ -54,6 +54,7 @@ struct rr_index {
     float* d_q = nullptr;        // staged queries [RR_MAX_BATCH][dim_pad]
     float norm_bound = -1.f;     // upper bound of the largest row norm; < 0: not computed (any write to the matrix resets it)
     float delta_bound = 0.f;     // ... and of the largest ||row - bf16(row)||
+    int32_t last_scan[4] = {0, 0, 0, 0};   // kernel id, template variant, queries in the launch, bf16 MFMA terms per dim
     int32_t scan_mode = 0;       // RR_SCAN_MODE_* (rr_index_set_scan_mode)
     void* d_x3 = nullptr;        // two-pass selection scratch of the split-operand scan (rr_x3_scratch)
     void* d_qplanes = nullptr;   // [3][64][384] bf16: one launch's queries split in three bf16 terms
@@ -61,6 +62,11 @@ struct rr_index {
     float* d_scores_out = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // last scan
+    // the K1 scratch is per handle: a call on another stream than the previous one first waits for the
+    // previous call's last kernel (event), so two host threads on different streams cannot overlap on it
+    hipEvent_t ev_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_done = false;
     bool timing_valid = false;
     static const int kRing = 512;               // event pairs around every scan launch
     hipEvent_t ring0[kRing] = {}, ring1[kRing] = {};

@@ -1095,6 +1095,7 @@ static int rr_dense_chunk(rr_index* ix, const float* d_q, int nq, int pool, int6
     if (time_it) hipEventRecord(ix->ev0, st);
     const int slot = (int)(ix->ring_head % rr_index::kRing);
     hipEventRecord(ix->ring0[slot], st);
+    rr_scan_note(ix, 1, nq <= 1 ? 1 : nq <= 2 ? 2 : nq <= 4 ? 4 : 8, nq, 0);
     rr_scan_geom G;
     switch (nq) {
         case 1: G = rr_launch_scan<1>(ix, d_q, st); break;
@@ -1135,6 +1136,7 @@ static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool,
     G.qs = 16 * NQT;
     const int slot = (int)(ix->ring_head % rr_index::kRing);
     hipEventRecord(ix->ring0[slot], st);
+    rr_scan_note(ix, 6, NQT, nq, 0);
     hipLaunchKernelGGL((rr_scan_mfma_f32<NQT>), dim3((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), dim3(THREADS), 0, st,
                        reinterpret_cast<const f32x4*>(ix->d_matrix), G, d_q, ix->d_sims, ix->d_gmax, ix->d_smax);
     hipEventRecord(ix->ring1[slot], st);
@@ -1143,6 +1145,18 @@ static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool,
     hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
                        ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr);
     RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+// Orders this call's use of the handle's scratch behind the previous call's when the stream changed.
+static int rr_scratch_enter(rr_index* ix, hipStream_t st) {
+    if (ix->has_done && st != ix->last_stream) RR_HIP_TRY(hipStreamWaitEvent(st, ix->ev_done, 0));
+    return RR_OK;
+}
+static int rr_scratch_leave(rr_index* ix, hipStream_t st) {
+    RR_HIP_TRY(hipEventRecord(ix->ev_done, st));
+    ix->last_stream = st;
+    ix->has_done = true;
     return RR_OK;
 }
 
@@ -1229,11 +1243,15 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
+    int rc = rr_scratch_enter(ix, st);
+    if (rc) return rc;
     const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);   // kernels read whole query tiles
     const int64_t total = (int64_t)slots * ix->dim_pad;
     hipLaunchKernelGGL(rr_pad_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                        d_queries, ix->d_q, n_queries, ix->dim, ix->dim_pad, slots);
-    return rr_dense_topk_impl(ix, ix->d_q, n_queries, pool, d_out_rows, d_out_scores, st);
+    rc = rr_dense_topk_impl(ix, ix->d_q, n_queries, pool, d_out_rows, d_out_scores, st);
+    if (rc) return rc;
+    return rr_scratch_leave(ix, st);
 }
 
 extern "C" int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_queries, int32_t pool,
@@ -1258,6 +1276,8 @@ extern "C" int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_que
     // device's default stream unless they say otherwise: use that stream here too so two host
     // threads (one on each entry point) stay ordered on the scratch.
     hipStream_t st = nullptr;
+    int rce = rr_scratch_enter(ix, st);
+    if (rce) return rce;
     const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);   // kernels read whole query tiles
     RR_HIP_TRY(hipMemsetAsync(ix->d_q, 0, sizeof(float) * (size_t)slots * ix->dim_pad, st));
     RR_HIP_TRY(hipMemcpy2DAsync(ix->d_q, sizeof(float) * ix->dim_pad, h_queries,
@@ -1270,7 +1290,7 @@ extern "C" int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_que
     RR_HIP_TRY(hipMemcpyAsync(h_out_scores, ix->d_scores_out, sizeof(float) * (size_t)n_queries * eff,
                               hipMemcpyDeviceToHost, st));
     RR_HIP_TRY(hipStreamSynchronize(st));
-    return RR_OK;
+    return rr_scratch_leave(ix, st);
 }
 
 extern "C" int rr_index_last_scan_ms(rr_index* ix, float* out_ms) {
@@ -1280,6 +1300,13 @@ extern "C" int rr_index_last_scan_ms(rr_index* ix, float* out_ms) {
     RR_HIP_TRY(hipSetDevice(ix->device));
     RR_HIP_TRY(hipEventSynchronize(ix->ev1));
     RR_HIP_TRY(hipEventElapsedTime(out_ms, ix->ev0, ix->ev1));
+    return RR_OK;
+}
+
+extern "C" int rr_index_last_scan_info(rr_index* ix, int32_t* out8) {
+    RR_REQUIRE(ix && out8, "rr_index_last_scan_info: NULL argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    for (int i = 0; i < 8; ++i) out8[i] = i < 4 ? ix->last_scan[i] : 0;
     return RR_OK;
 }
 

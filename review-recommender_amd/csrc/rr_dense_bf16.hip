@@ -169,6 +169,7 @@ static rr_scan_geom rr_launch_scan_bf16(rr_index* ix, const float* d_q, hipStrea
 int rr_dense_chunk_bf16(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                         float* d_scores, hipStream_t st) {
     const int slot = rr_scan_events_begin(ix, st);
+    rr_scan_note(ix, 2, nq <= 1 ? 1 : nq <= 2 ? 2 : nq <= 4 ? 4 : 8, nq, 0);
     rr_scan_geom G;
     switch (nq) {
         case 1: G = rr_launch_scan_bf16<1>(ix, d_q, st); break;
@@ -306,6 +307,7 @@ static int rr_dense_chunk_mfma_bf16_t(rr_index* ix, const float* d_q, int nq, in
     rr_scan_geom G = rr_make_geom(ix, waves / 4);
     G.qs = 16 * NQT;
     const int slot = rr_scan_events_begin(ix, st);
+    rr_scan_note(ix, 7, NQT, nq, 0);
     hipLaunchKernelGGL((rr_scan_mfma_bf16<NQT>), dim3((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), dim3(THREADS),
                        0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G, d_q, ix->d_sims, ix->d_gmax, ix->d_smax);
     rr_scan_events_end(ix, slot, st);

@@ -482,6 +482,7 @@ static int rr_dense_chunk_flt_t(rr_index* ix, const float* d_q, int nq, int pool
                        A_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     const int slot = rr_scan_events_begin(ix, st);
+    rr_scan_note(ix, 5, NQ2, nq, 1);
     hipLaunchKernelGGL((rr_scan_flt<NQ2, A_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
                        reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax, X.eps, nq);
     rr_scan_events_end(ix, slot, st);

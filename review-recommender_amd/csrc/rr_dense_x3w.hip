@@ -456,6 +456,7 @@ static int rr_dense_chunk_x3w_t(rr_index* ix, const float* d_q, int nq, int pool
     rr_launch_split_queries(d_q, planes, QN, A_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL, st);
     if (rr_x3_stored_path(ix)) {
         const int slot = rr_scan_events_begin(ix, st);
+    rr_scan_note(ix, 4, NQ2, nq, A_BF16 ? 3 : 6);
         hipLaunchKernelGGL((rr_scan_x3w<NQ2, A_BF16, true>), grid, block, 0, st, mat, G, pl4, ix->d_sims,
                            ix->d_gmax, ix->d_smax, (const int32_t*)nullptr, 0);
         rr_scan_events_end(ix, slot, st);
@@ -464,6 +465,7 @@ static int rr_dense_chunk_x3w_t(rr_index* ix, const float* d_q, int nq, int pool
         return RR_OK;
     }
     const int slot = rr_scan_events_begin(ix, st);
+    rr_scan_note(ix, 4, NQ2, nq, A_BF16 ? 3 : 6);
     hipLaunchKernelGGL((rr_scan_x3w<NQ2, A_BF16, false>), grid, block, 0, st, mat, G, pl4, ix->d_sims,
                        ix->d_gmax, ix->d_smax, (const int32_t*)nullptr, 0);
     rr_scan_events_end(ix, slot, st);

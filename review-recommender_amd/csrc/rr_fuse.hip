@@ -281,7 +281,12 @@ __global__ __launch_bounds__(RR_FUSE_THREADS) void rr_fuse(
         const float t_bm25 = fp.w_bm2532 * c_bm25[i];
         float s32 = t_dense + t_bm25;
         double s64;
-        if (fp.p.rerank_active) {
+        if (fp.p.bm25_f64) {
+            // CLI without a BM25 artefact: `cand["_bm25"] = 0.0` is a float64 column (app/test.py:252), so the
+            // sum is float64 from its second term on and a float32 rerank product is widened before it is added
+            s64 = (double)t_dense + fp.p.w_bm25 * 0.0;
+            s64 = fp.p.rerank_active ? s64 + (double)(fp.w_rerank32 * c_rr[i]) : s64 + fp.p.w_rerank * 0.0;
+        } else if (fp.p.rerank_active) {
             s32 = s32 + fp.w_rerank32 * c_rr[i];
             s64 = (double)s32;
         } else {

@@ -18,6 +18,7 @@ struct rr_reviews {
     float* d_emb = nullptr;          // n_reviews x dim_pad, rows l2-normalised
     int64_t* d_indptr = nullptr;     // n_products + 1
     int32_t* d_ids = nullptr;        // review ids, ascending per product
+    int32_t* d_cut = nullptr;        // [RR_MAX_BATCH] per-query review-id cut of rr_reviews_best_cut_dev
     std::mutex mu;
 };
 
@@ -25,12 +26,14 @@ struct rr_reviews {
 __global__ __launch_bounds__(256) void rr_best_review(
     const f32x4* __restrict__ emb, int nf, const int64_t* __restrict__ indptr, const int32_t* __restrict__ ids,
     int64_t n_products, const float* __restrict__ queries, int dim, const int64_t* __restrict__ rows, int pool,
-    int64_t row_offset, int32_t max_review_id, float* __restrict__ best_score, int32_t* __restrict__ best_id) {
+    int64_t row_offset, int32_t max_review_id_all, const int32_t* __restrict__ cuts,
+    float* __restrict__ best_score, int32_t* __restrict__ best_id) {
     __shared__ uint64_t wbest[4];
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int sub = lane & 15, grp = lane >> 4;
     const int q = blockIdx.y, c = blockIdx.x;
+    const int32_t max_review_id = cuts ? cuts[q] : max_review_id_all;
     const int64_t prod = rows[(int64_t)q * pool + c] - row_offset;
     uint64_t best = 0;                                    // (score key << 32) | ~review id ; 0 = none
     if (prod >= 0 && prod < n_products) {
@@ -77,6 +80,51 @@ __global__ __launch_bounds__(256) void rr_best_review(
     }
 }
 
+// The reference scores only the first `max_rows` reviews, in file order, of all reviews whose sku is among
+// the query's candidates (`sub_meta.iloc[:max_rows]`, app/app_product_search.py:342-345, app/test.py:200-203).
+// File order = review id, so the cut is a review-id threshold: the max_rows-th smallest id in the union of
+// the candidates' (ascending) lists; n_reviews (= keep all) when the union is not longer than max_rows.
+// One workgroup per query: bisection on the id, counts by binary search in every candidate's list.
+__global__ __launch_bounds__(256) void rr_reviews_cut(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ ids, int64_t n_products,
+    const int64_t* __restrict__ rows, int pool, int64_t row_offset, int64_t max_rows, int64_t n_reviews,
+    int32_t* __restrict__ cut) {
+    __shared__ long long wsum[4];
+    const int tid = threadIdx.x, q = blockIdx.x;
+    auto count_le = [&](int64_t T) -> long long {      // reviews with id <= T among the candidates (block-wide)
+        long long c = 0;
+        for (int i = tid; i < pool; i += 256) {
+            const int64_t prod = rows[(int64_t)q * pool + i] - row_offset;
+            if (prod < 0 || prod >= n_products) continue;
+            int64_t lo = indptr[prod], hi = indptr[prod + 1];
+            const int64_t s = lo;
+            while (lo < hi) {                             // first entry > T
+                const int64_t mid = (lo + hi) >> 1;
+                if ((int64_t)ids[mid] <= T) lo = mid + 1; else hi = mid;
+            }
+            c += lo - s;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) wsum[tid >> 6] = c;
+        __syncthreads();
+        return wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    };
+    int32_t out;
+    if (max_rows <= 0) out = -1;
+    else if (count_le(n_reviews) <= max_rows) out = (int32_t)n_reviews;
+    else {
+        int64_t lo = 0, hi = n_reviews - 1;               // smallest T with count_le(T) >= max_rows
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (count_le(mid) >= max_rows) hi = mid; else lo = mid + 1;
+        }
+        out = (int32_t)lo;
+    }
+    if (tid == 0) cut[q] = out;
+}
+
 __global__ void rr_reviews_l2norm(float* __restrict__ mat, int64_t n_rows, int dim_pad, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -93,7 +141,7 @@ __global__ void rr_reviews_l2norm(float* __restrict__ mat, int64_t n_rows, int d
 extern "C" int rr_reviews_destroy(rr_reviews* rv) {
     if (!rv) return RR_OK;
     hipSetDevice(rv->device);
-    hipFree(rv->d_emb); hipFree(rv->d_indptr); hipFree(rv->d_ids);
+    hipFree(rv->d_emb); hipFree(rv->d_indptr); hipFree(rv->d_ids); hipFree(rv->d_cut);
     delete rv;
     return RR_OK;
 }
@@ -114,6 +162,7 @@ extern "C" int rr_reviews_create(const float* h_emb, int64_t n_reviews, int32_t 
     hipError_t e = hipMalloc((void**)&rv->d_emb, sizeof(float) * (size_t)n_reviews * rv->dim_pad);
     if (e == hipSuccess) e = hipMalloc((void**)&rv->d_indptr, sizeof(int64_t) * (size_t)(n_products + 1));
     if (e == hipSuccess) e = hipMalloc((void**)&rv->d_ids, sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&rv->d_cut, sizeof(int32_t) * RR_MAX_BATCH);
     if (e == hipSuccess && rv->dim_pad != dim) e = hipMemset(rv->d_emb, 0, sizeof(float) * (size_t)n_reviews * rv->dim_pad);
     if (e == hipSuccess)
         e = hipMemcpy2D(rv->d_emb, sizeof(float) * rv->dim_pad, h_emb, sizeof(float) * dim, sizeof(float) * dim,
@@ -143,8 +192,26 @@ extern "C" int rr_reviews_best_dev(rr_reviews* rv, const float* d_queries, int32
     RR_HIP_TRY(hipSetDevice(rv->device));
     hipLaunchKernelGGL(rr_best_review, dim3((unsigned)pool, (unsigned)n_queries), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f32x4*>(rv->d_emb), rv->dim_pad / 64, rv->d_indptr, rv->d_ids,
-                       rv->n_products, d_queries, rv->dim, d_rows, pool, row_offset, max_review_id, d_best_score,
-                       d_best_id);
+                       rv->n_products, d_queries, rv->dim, d_rows, pool, row_offset, max_review_id,
+                       (const int32_t*)nullptr, d_best_score, d_best_id);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+extern "C" int rr_reviews_best_cut_dev(rr_reviews* rv, const float* d_queries, int32_t n_queries,
+                                       const int64_t* d_rows, int32_t pool, int64_t row_offset,
+                                       int64_t max_rows, float* d_best_score, int32_t* d_best_id, void* stream) {
+    RR_REQUIRE(rv && d_queries && d_rows && d_best_score && d_best_id, "rr_reviews_best_cut_dev: NULL argument");
+    RR_REQUIRE(n_queries >= 1 && n_queries <= RR_MAX_BATCH && pool >= 1 && pool <= RR_MAX_POOL,
+               "rr_reviews_best_cut_dev: n_queries %d / pool %d out of range", n_queries, pool);
+    std::lock_guard<std::mutex> lk(rv->mu);
+    RR_HIP_TRY(hipSetDevice(rv->device));
+    hipLaunchKernelGGL(rr_reviews_cut, dim3((unsigned)n_queries), dim3(256), 0, (hipStream_t)stream, rv->d_indptr,
+                       rv->d_ids, rv->n_products, d_rows, pool, row_offset, max_rows, rv->n_reviews, rv->d_cut);
+    hipLaunchKernelGGL(rr_best_review, dim3((unsigned)pool, (unsigned)n_queries), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(rv->d_emb), rv->dim_pad / 64, rv->d_indptr, rv->d_ids,
+                       rv->n_products, d_queries, rv->dim, d_rows, pool, row_offset, 0, (const int32_t*)rv->d_cut,
+                       d_best_score, d_best_id);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }

@@ -86,7 +86,8 @@ class HybridSearcher:
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("no GPU visible: the search path runs on the device only")
         self.device = torch.device("cuda", index.device)
-        self._term_cache = {}
+        self._stage_slots = [{"host": None, "dev": None, "event": None} for _ in range(8)]
+        self._stage_next = 0
 
     # -------------------------------------------------------------- device steps
     def _stream(self):
@@ -111,7 +112,9 @@ class HybridSearcher:
         """K2 on device tensors: float32 (B, pool) raw BM25 at the candidate rows."""
         torch = _torch()
         B, pool = rows_dev.shape
-        if self.bm25 is None or not any(len(t) for t in term_id_lists):
+        flat_form = isinstance(term_id_lists, tuple) and len(term_id_lists) == 2 and isinstance(term_id_lists[1], np.ndarray)
+        empty = (len(term_id_lists[0]) == 0) if flat_form else not any(len(t) for t in term_id_lists)
+        if self.bm25 is None or empty:
             # no index / no tokens -> zeros (app/app_product_search.py:202,204)
             if out is None:
                 return torch.zeros((B, pool), dtype=torch.float32, device=self.device)
@@ -127,25 +130,37 @@ class HybridSearcher:
         return out
 
     def _stage_terms(self, term_id_lists):
-        """Token ids of a batch as device arrays (flat ids + offsets).  A batch object that
-        is searched again (bench.py replays its query sets) is staged once."""
+        """Token ids of a batch as device arrays (flat ids + offsets), uploaded on every call through a
+        small ring of pinned host buffers (one async copy per batch; nothing is cached across calls, so a
+        caller may reuse and mutate its lists).  ``term_id_lists`` is a sequence of per-query id
+        sequences, or an already flattened ``(ids int32, offsets int32[B+1])`` pair of numpy arrays."""
         torch = _torch()
-        hit = self._term_cache.get(id(term_id_lists))
-        if hit is not None and hit[0] is term_id_lists:
-            return hit[1], hit[2]
-        B = len(term_id_lists)
-        off = np.zeros(B + 1, dtype=np.int32)
-        for i, t in enumerate(term_id_lists):
-            if len(t) > 64:
-                raise ValueError("a query may carry at most 64 tokens (RR_MAX_QTERMS)")
-            off[i + 1] = off[i] + len(t)
-        flat = np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in term_id_lists])
-        ids_dev = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.int32)).to(self.device)
-        off_dev = torch.from_numpy(off).to(self.device)
-        if len(self._term_cache) >= 64:
-            self._term_cache.clear()
-        self._term_cache[id(term_id_lists)] = (term_id_lists, ids_dev, off_dev)
-        return ids_dev, off_dev
+        if isinstance(term_id_lists, tuple) and len(term_id_lists) == 2 and isinstance(term_id_lists[1], np.ndarray):
+            flat = np.ascontiguousarray(term_id_lists[0], dtype=np.int32).reshape(-1)
+            off = np.ascontiguousarray(term_id_lists[1], dtype=np.int32).reshape(-1)
+        else:
+            B = len(term_id_lists)
+            off = np.zeros(B + 1, dtype=np.int32)
+            np.cumsum([len(t) for t in term_id_lists], out=off[1:])
+            flat = (np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in term_id_lists])
+                    if off[-1] else np.zeros(0, dtype=np.int32))
+        n_off, n_ids = off.shape[0], flat.shape[0]
+        need = n_off + max(n_ids, 1)
+        slot = self._stage_slots[self._stage_next % len(self._stage_slots)]
+        self._stage_next += 1
+        if slot["host"] is None or slot["host"].numel() < need:
+            cap = max(need, 4096)
+            slot["host"] = torch.empty(cap, dtype=torch.int32).pin_memory()
+            slot["dev"] = torch.empty(cap, dtype=torch.int32, device=self.device)
+            slot["event"] = torch.cuda.Event()
+        else:
+            slot["event"].synchronize()          # the copy that last used this pinned buffer has finished
+        h = slot["host"].numpy()
+        h[:n_off] = off
+        h[n_off:n_off + n_ids] = flat
+        slot["dev"][:need].copy_(slot["host"][:need], non_blocking=True)
+        slot["event"].record(torch.cuda.current_stream(self.device))
+        return slot["dev"][n_off:n_off + max(n_ids, 1)], slot["dev"][:n_off]
 
     def fuse(self, params: "_lib.FuseParams", B: int, rows, dense, bm25, meta=None,
              rerank=None, best=None, gate=None):
@@ -166,24 +181,26 @@ class HybridSearcher:
     # -------------------------------------------------------------- one batch
     @staticmethod
     def make_params(w: FusionWeights, k: int, pool: int, n_candidates: int, rerank_k: int,
-                    cand_per_rank: int = 0, stride_bytes: int = 0) -> "_lib.FuseParams":
+                    cand_per_rank: int = 0, stride_bytes: int = 0, bm25_f64: bool = False) -> "_lib.FuseParams":
         return _lib.FuseParams(
             w_dense=w.w_dense, w_bm25=w.w_bm25, w_rerank=w.w_rerank, w_prior=w.w_prior,
             w_best=w.w_best, prior_C=w.prior_C, min_reviews=int(w.min_reviews),
             trust_sat=int(w.trust_sat), apply_trust=int(bool(w.apply_trust)),
             rerank_active=int(rerank_k > 0), rerank_k=int(rerank_k), k=int(k),
             n_candidates=int(n_candidates), pool=int(pool), cand_per_rank=int(cand_per_rank),
-            _pad=0, cand_rank_stride_bytes=int(stride_bytes))
+            bm25_f64=int(bool(bm25_f64)), cand_rank_stride_bytes=int(stride_bytes))
 
     def search_batch(self, qvecs: np.ndarray, term_id_lists: Optional[Sequence[Sequence[int]]],
                      k: int, rerank_k: int = 0, weights: Optional[FusionWeights] = None,
                      pool_floor: int = APP_POOL_FLOOR,
                      gate_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None,
                      rerank_fn: Optional[Callable[[np.ndarray], np.ndarray]] = None,
-                     bm25_mode: str = "forward", reviews=None, max_scan: int = 0) -> BatchResult:
+                     bm25_mode: str = "forward", reviews=None, max_scan: int = 0,
+                     bm25_f64: bool = False) -> BatchResult:
         """qvecs (B, dim) float32; term_id_lists: per-query BM25 token ids (None = no BM25).
         gate_fn / rerank_fn map the (B, pool) pool rows to (B, pool) float32 gate factors /
-        (B, rr_k) raw reranker scores; they run on the host between K2 and K3."""
+        (B, rr_k) raw reranker scores; they run on the host between K2 and K3.
+        ``bm25_f64``: the CLI flavour without a BM25 artefact (float64 zeros column, app/test.py:252)."""
         torch = _torch()
         w = weights or FusionWeights()
         q = np.ascontiguousarray(qvecs, dtype=np.float32)
@@ -206,16 +223,14 @@ class HybridSearcher:
             best_ids = None
             rows_h = None
             if reviews is not None:
-                # best review per candidate (csrc/rr_reviews.hip); the max_rows cut needs the rows on the host
-                rows_h = rows.cpu().numpy()
-                best = torch.zeros((B, pool), dtype=torch.float32, device=self.device)
-                best_ids = torch.full((B, pool), -1, dtype=torch.int32, device=self.device)
-                for b in range(B):      # the cut differs per query
-                    cut = reviews.cut_for(rows_h[b] - self.index.row_offset, max_scan)
-                    _lib.check(self.lib.rr_reviews_best_dev(
-                        reviews.handle, C.c_void_p(q_dev[b:b + 1].data_ptr()), 1, C.c_void_p(rows[b:b + 1].data_ptr()),
-                        pool, self.index.row_offset, cut, C.c_void_p(best[b:b + 1].data_ptr()),
-                        C.c_void_p(best_ids[b:b + 1].data_ptr()), self._stream()), "rr_reviews_best_dev")
+                # best review per candidate (csrc/rr_reviews.hip), the whole batch in one call; the
+                # reference's iloc[:max_rows] cut is evaluated per query on the device
+                best = torch.empty((B, pool), dtype=torch.float32, device=self.device)
+                best_ids = torch.empty((B, pool), dtype=torch.int32, device=self.device)
+                _lib.check(self.lib.rr_reviews_best_cut_dev(
+                    reviews.handle, C.c_void_p(q_dev.data_ptr()), B, C.c_void_p(rows.data_ptr()), pool,
+                    self.index.row_offset, int(max_scan), C.c_void_p(best.data_ptr()),
+                    C.c_void_p(best_ids.data_ptr()), self._stream()), "rr_reviews_best_cut_dev")
             if gate_fn is not None or (rerank_fn is not None and rr_k > 0):
                 rows_h = rows.cpu().numpy() if rows_h is None else rows_h
                 if gate_fn is not None:
@@ -225,8 +240,9 @@ class HybridSearcher:
                     r = np.zeros((B, pool), dtype=np.float32)
                     r[:, :rr_k] = np.asarray(rerank_fn(rows_h[:, :rr_k]), dtype=np.float32)
                     rerank = torch.from_numpy(r).to(self.device)
-            params = self.make_params(w, k_eff, pool, pool, rr_k)
-            out_rows, cols, order = self.fuse(params, B, rows, dense, bm, None, rerank, best, gate)
+            params = self.make_params(w, k_eff, pool, pool, rr_k, bm25_f64=bm25_f64 and self.bm25 is None)
+            out_rows, cols, order = self.fuse(params, B, rows, dense, None if params.bm25_f64 else bm, None,
+                                              rerank, best, gate)
             res = BatchResult(out_rows.cpu().numpy(), cols.cpu().numpy(), order.cpu().numpy(),
                               dense.cpu().numpy(), bm.cpu().numpy(), pool, k_eff)
             if best_ids is not None:
@@ -283,9 +299,11 @@ class SearchEngine:
         """Loads product_emb.npy / product_emb_meta.parquet / product_bm25.pkl from ``data_dir``
         (the reference's data/processed layout, app/test.py:21-26) and l2-normalises the rows on
         the GPU like the reference's loaders do on the host (app/test.py:144)."""
-        from .artifacts import load_artifacts
+        from .artifacts import load_artifacts, load_reviews
         meta, emb, blob = load_artifacts(data_dir)
         kw.setdefault("normalize", True)
+        if "reviews" not in kw:
+            kw["reviews"] = load_reviews(data_dir)     # None when reviews_with_embeddings.parquet is absent
         return cls(meta, emb, blob, **kw)
 
     # app: sku -> last position, missing -> 0.0 score (app/app_product_search.py:207-208)
@@ -361,8 +379,9 @@ class SearchEngine:
             pool_floor=APP_POOL_FLOOR if app else CLI_POOL_FLOOR,
             gate_fn=gate_fn if groups else None,
             rerank_fn=self._rerank_fn(query) if rerank_k > 0 else None,
-            reviews=self.reviews if use_snips else None, max_scan=max_scan)
-        frame = self._frame(res, 0)
+            reviews=self.reviews if use_snips else None, max_scan=max_scan,
+            bm25_f64=not app)
+        frame = self._frame(res, 0, rerank_k > 0)
         snips = {}
         if res.best_ids is not None:
             skus = self.meta["sku"].astype(str).iloc[res.pool_rows[0]].tolist()
@@ -372,14 +391,19 @@ class SearchEngine:
                                                               APP_POOL_FLOOR if app else CLI_POOL_FLOOR)}
         return frame, snips, dbg
 
-    def _frame(self, res: BatchResult, b: int) -> pd.DataFrame:
+    def _frame(self, res: BatchResult, b: int, rerank_active: bool = False) -> pd.DataFrame:
         top = res.order[b].astype(np.int64)
         out = self.meta.iloc[res.pool_rows[b][top]].reset_index(drop=True).copy()
         for j, name in enumerate(COLUMN_NAMES):
             col = res.columns[b, j, top]
             if name == "_trust" and self.flavour == "cli":
                 continue   # the CLI has no trust column (app/test.py:308)
-            out[name] = col.astype(np.float32) if name in _FLOAT32_COLUMNS else col
+            # `_rerank` is the float32 array z when rerank_k > 0, else the float64 scalar column 0.0
+            # (app/app_product_search.py:279-282); `_bm25` is float64 zeros in the CLI without an artefact
+            f32 = name in _FLOAT32_COLUMNS or (name == "_rerank" and rerank_active)
+            if name == "_bm25" and self.flavour == "cli" and self.searcher.bm25 is None:
+                f32 = False
+            out[name] = col.astype(np.float32) if f32 else col
         return out
 
     def search(self, query: str, k: int = 10, alpha: float = 0.5, *,
@@ -409,12 +433,14 @@ def cosine_similarity_search(query_vector: np.ndarray, embeddings_matrix: np.nda
     return rows[0], scores[0]
 
 
-def cli_rows(frame: pd.DataFrame) -> List[Dict]:
-    """The CLI's JSON row schema (app/test.py:312-328), 4-dp rounding."""
+def cli_rows(frame: pd.DataFrame, snips: Optional[Dict] = None) -> List[Dict]:
+    """The CLI's JSON row schema (app/test.py:312-328), 4-dp rounding; ``snips`` is run_search's
+    second return value (sku -> best review)."""
     rows = []
     for _, r in frame.iterrows():
         n = r.get("n_reviews", np.nan)
         a = r.get("avg_stars", np.nan)
+        snip = snips.get(str(r["sku"])) if snips else None
         rows.append({
             "sku": str(r["sku"]), "score": round(float(r["_final"]), 4),
             "dense": round(float(r["_dense"]), 4), "bm25": round(float(r["_bm25"]), 4),
@@ -422,5 +448,6 @@ def cli_rows(frame: pd.DataFrame) -> List[Dict]:
             "bestrev": round(float(r["_best"]), 4),
             "n_reviews": int(n) if pd.notna(n) else 0,
             "avg_stars": round(float(a), 2) if pd.notna(a) else None,
-            "snippet_stars": None, "snippet": None})
+            "snippet_stars": float(snip["stars"]) if snip and snip.get("stars") is not None else None,
+            "snippet": snip["text"] if snip else None})
     return rows

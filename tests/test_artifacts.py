@@ -88,3 +88,49 @@ def test_cli_end_to_end_matches_oracle(tmp_path, capsys):
         for key in ("score", "dense", "bm25", "rerank", "prior", "bestrev"):
             assert abs(g[key] - e[key]) <= 1.01e-4          # 4-dp rounding of values within 1e-5
         assert g["n_reviews"] == e["n_reviews"] and g["avg_stars"] == e["avg_stars"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_snippets", [False, True])
+def test_cli_scores_snippets_when_the_review_file_exists(tmp_path, capsys, no_snippets):
+    """app/test.py:271-289,312-336: with reviews_with_embeddings.parquet present the CLI blends the best
+    review (w_best) and prints / writes its snippet unless --no-snippets is given."""
+    from oracle.bm25 import BM25OkapiOracle
+    from oracle.pipeline import cli_rows, run_search_oracle
+    from review_recommender_amd.cli import main
+    meta, V = world(2000, 19)
+    blob = artifacts.build_bm25_blob(meta)
+    artifacts.save_artifacts(tmp_path, meta, V, blob)
+    rng = np.random.default_rng(3)
+    n_rev = 6000
+    owner = rng.integers(0, len(meta), n_rev)
+    E = (V[owner] * 3 + rng.standard_normal((n_rev, 384)).astype(np.float32) * 0.05).astype(np.float32)
+    reviews = pd.DataFrame({"sku": meta["sku"].values[owner], "text": [f"review text {i} " * 40 for i in range(n_rev)],
+                            "stars": rng.integers(1, 6, n_rev).astype(np.float64)})
+    artifacts.save_reviews(tmp_path, reviews, E)
+    back = artifacts.load_reviews(tmp_path)
+    assert back[0].equals(reviews) and np.array_equal(back[1], E)
+    qv = synth.unit_rows(1, 384, 11)[0]
+    np.save(tmp_path / "q.npy", qv)
+    out = tmp_path / "out.json"
+    argv = ["-q", "wireless cat socks", "-k", "8", "--rerank_k", "0", "--data-dir", str(tmp_path),
+            "--qvec-npy", str(tmp_path / "q.npy"), "--json-out", str(out), "--max-reviews-scan", "250"]
+    rc = main(argv + (["--no-snippets"] if no_snippets else []))
+    printed = capsys.readouterr().out
+    got = json.loads(out.read_text())
+    want, snips, _, _ = run_search_oracle(query="wireless cat socks", qvec=qv, meta=meta, V=V,
+                                          bm25=BM25OkapiOracle(blob["corpus"]), bm25_skus=blob["skus"], k=8,
+                                          rerank_k=0, w_dense=0.55, w_bm25=0.15, w_rerank=0.15, w_prior=0.10,
+                                          w_best=0.05, prior_C=20.0, gate_penalty=0.5, flavour="cli",
+                                          use_snips=not no_snippets, max_scan=250, reviews=(reviews, E))
+    exp = cli_rows(want, snips)
+    assert rc == 0 and [r["sku"] for r in got["results"]] == [r["sku"] for r in exp]
+    for g, e in zip(got["results"], exp):
+        assert g["snippet"] == e["snippet"] and g["snippet_stars"] == e["snippet_stars"]
+        for key in ("score", "bestrev"):
+            assert abs(g[key] - e[key]) <= 1.01e-4
+    if no_snippets:
+        assert all(r["snippet"] is None and r["bestrev"] == 0 for r in got["results"])
+    else:
+        assert any(r["snippet"] for r in got["results"]) and "review text" in printed
+        assert all(r["snippet"] is None or len(r["snippet"]) <= 400 for r in got["results"])

@@ -75,3 +75,25 @@ def test_bf16_hybrid_pipeline_matches_oracle():
                                           w_best=0.0, prior_C=20.0, min_reviews=8, gate_penalty=1.0)
         assert got["sku"].tolist() == want["sku"].tolist()
         np.testing.assert_allclose(got["_final"].values, want["_final"].values, atol=1e-5, rtol=0)
+
+
+def test_bf16_row_norm_bound_follows_rows_uploaded_after_a_batched_search(hip):
+    """rr_index_upload_rows_f32 must reset the cached row-norm bound for bf16 storage too.
+    Small-norm rows first, one batched (filter-scan) search caches their bound; larger rows are then
+    uploaded over them and the batched answer must still equal the single-query scan's."""
+    import ctypes as C
+    from review_recommender_amd import _lib
+    n = 60_000
+    small = (synth.unit_rows(n, 384, 41) * 0.05).astype(np.float32)
+    big = (synth.unit_rows(n, 384, 42) * 3.0).astype(np.float32)
+    Q = synth.unit_rows(40, 384, 43)
+    ix = ProductIndex.from_rows(small, dtype="bf16")
+    ix.dense_topk(Q, 150)                                     # caches the bound of the small rows
+    _lib.check(hip.rr_index_upload_rows_f32(ix.handle, 0, n, _lib.ptr(big), 0.0), "upload")
+    rows_b, scores_b = ix.dense_topk(Q, 150)                  # batched: filter scan with the bound
+    for i in range(0, 40, 7):
+        r1, s1 = ix.dense_topk(Q[i:i + 1], 150)               # single-query scan: no bound involved
+        assert np.array_equal(rows_b[i], r1[0]) and np.array_equal(scores_b[i], s1[0])
+        assert_topk_matches(rows_b[i], scores_b[i], OD.sims_float64(OD.round_to_bf16(big), Q[i]), 150,
+                            score_tol=3e-5)
+    ix.close()

@@ -258,3 +258,66 @@ def test_one_engine_shared_by_threads(world):
         [t.join() for t in threads]
         for i in range(12):
             assert got[i][0] == want[i][0] and np.array_equal(got[i][1], want[i][1])
+
+
+def test_cli_without_bm25_artefact_blends_in_float64_from_the_second_term(world):
+    """in the CLI, `cand["_bm25"] = 0.0` (no artefact, app/test.py:252) is a float64 column, so
+    the blend is float64 from the second term on even when the float32 rerank column is active; the
+    fusion kernel must follow (rr_fuse_params.bm25_f64) and the frame's dtypes too."""
+    ce = FakeCrossEncoder()
+    engine = SearchEngine(world["meta"], world["V"], None, cross_encoder=ce, normalize=False, flavour="cli")
+    cfg = dict(k=100, rerank_k=60, w_dense=0.37, w_bm25=0.21, w_rerank=0.33, w_prior=0.17, w_best=0.0,
+               prior_C=20.0, min_reviews=8, gate_penalty=1.0)
+    differs = 0
+    for seed, query in enumerate(QUERIES):
+        qvec = synth.unit_rows(1, 384, 400 + seed)[0]
+        want, _, _, cand = run_search_oracle(query=query, qvec=qvec, meta=world["meta"], V=world["V"], bm25=None,
+                                             flavour="cli", rerank_fn=(lambda pairs: ce.predict(pairs)), **cfg)
+        got, _, dbg = engine.run_search(query, cfg["k"], cfg["rerank_k"], cfg["w_dense"], cfg["w_bm25"],
+                                        cfg["w_rerank"], cfg["w_prior"], cfg["w_best"], cfg["prior_C"], False, 0,
+                                        cfg["min_reviews"], cfg["gate_penalty"], qvec=qvec)
+        assert dbg["bm25_active"] is False
+        assert got["_bm25"].dtype == want["_bm25"].dtype == np.float64
+        assert got["_rerank"].dtype == want["_rerank"].dtype == np.float32
+        g, w = got.set_index("sku")["_final"], want.set_index("sku")["_final"]
+        common = [s_ for s_ in g.index if s_ in w.index]
+        assert len(common) >= cfg["k"] - 2
+        assert np.array_equal(g.loc[common].values, w.loc[common].values)        # bit-exact finals
+        s32 = np.float32(cfg["w_dense"]) * cand["_dense"].values + np.float32(cfg["w_rerank"]) * cand["_rerank"].values
+        alt = (s32.astype(np.float64) + cfg["w_prior"] * cand["_prior"].values).astype(np.float32)
+        differs += int(np.any(alt != cand["_final"].values))
+    assert differs > 0        # the float32-first order would not have produced these finals
+
+
+def test_query_longer_than_64_tokens(world):
+    """get_scores has no token limit (a pasted paragraph is a legal query); K2 takes such a query in
+    several 64-token passes whose running float64 sum keeps the token order."""
+    engine = SearchEngine(world["meta"], world["V"], world["blob"], normalize=False)
+    words = [w for doc in world["blob"]["corpus"][:40] for w in doc][:150]
+    query = " ".join(words)
+    qv = synth.unit_rows(1, 384, 91)[0]
+    cfg = CONFIGS["north_star_alpha"]
+    got, _, dbg = engine.run_search(query, cfg["k"], 0, 0.5, 0.5, 0, 0, 0, 20.0, False, 0, 8, 1.0, qvec=qv)
+    assert len(dbg["tokens"]) > 64
+    want, _, _, cand = run_search_oracle(query=query, qvec=qv, meta=world["meta"], V=world["V"],
+                                         bm25=world["ora_bm25"], bm25_skus=world["blob"]["skus"], **cfg)
+    assert got["sku"].tolist() == want["sku"].tolist()
+    assert np.array_equal(got["_bm25"].values, want["_bm25"].values)
+    np.testing.assert_allclose(got["_final"].values, want["_final"].values, atol=TOL, rtol=0)
+
+
+def test_token_lists_are_staged_on_every_call(world):
+    """a caller that reuses and mutates one list object between calls must get the new ids."""
+    engine = SearchEngine(world["meta"], world["V"], world["blob"], normalize=False)
+    bm = engine.searcher.bm25
+    Q = synth.unit_rows(2, 384, 92)
+    w = FusionWeights(0.5, 0.5, 0.0, 0.0, 0.0)
+    lists = [bm.term_ids(["wireless", "mug"]), bm.term_ids(["cat"])]
+    a = engine.searcher.search_batch(Q, lists, 20, 0, w)
+    lists[0] = bm.term_ids(["socks", "blue"])            # same outer list object, new content
+    b = engine.searcher.search_batch(Q, lists, 20, 0, w)
+    c = engine.searcher.search_batch(Q, [bm.term_ids(["socks", "blue"]), bm.term_ids(["cat"])], 20, 0, w)
+    assert np.array_equal(b.bm25_raw, c.bm25_raw) and not np.array_equal(a.bm25_raw[0], b.bm25_raw[0])
+    flat = (np.concatenate(lists).astype(np.int32), np.array([0, len(lists[0]), len(lists[0]) + len(lists[1])], np.int32))
+    d = engine.searcher.search_batch(Q, flat, 20, 0, w)
+    assert np.array_equal(d.bm25_raw, c.bm25_raw)

@@ -64,3 +64,26 @@ def test_no_review_index_means_empty_snips():
     qv = synth.unit_rows(1, 384, 5)[0]
     got, snips, _ = engine.run_search("mug", 5, 0, 1.0, 0, 0, 0, 0.5, 20.0, True, 1000, 8, 1.0, qvec=qv)
     assert snips == {} and np.all(got["_best"] == 0)
+
+
+@pytest.mark.parametrize("max_scan", [300000, 150, 37, 1, 0])
+def test_batched_snippets_with_the_per_query_cut_on_the_device(max_scan):
+    """One rr_reviews_best_cut_dev call for a whole batch (no host round trip for the iloc[:max_rows] cut):
+    per query the snippets must be the ones the oracle's _best_snippets finds for that query alone."""
+    from oracle.dense import cosine_similarity_search
+    from oracle.pipeline import best_snippets_oracle
+    from review_recommender_amd.engine import FusionWeights
+    meta, V, reviews, E = make(2500, 15000, seed=9)
+    engine = SearchEngine(meta, V, None, normalize=False, reviews=(reviews, E))
+    Q = synth.unit_rows(9, 384, 77)
+    w = FusionWeights(0.6, 0.0, 0.0, 0.0, 0.4, gate_penalty=1.0)
+    res = engine.searcher.search_batch(Q, None, 10, 0, w, reviews=engine.reviews, max_scan=max_scan)
+    skus = meta["sku"].astype(str)
+    for b in range(9):
+        rows_o, _ = cosine_similarity_search(Q[b], V, 150)
+        assert np.array_equal(rows_o, res.pool_rows[b])
+        want = best_snippets_oracle(reviews, E, Q[b], skus.iloc[rows_o].tolist(), max_rows=max_scan)
+        got = engine.reviews.snippets(skus.iloc[res.pool_rows[b]].tolist(), res.best_ids[b], res.best_raw[b])
+        assert set(got) == set(want)
+        for s_, w_ in want.items():
+            assert got[s_]["text"] == w_["text"] and abs(got[s_]["score"] - w_["score"]) < 1e-5
