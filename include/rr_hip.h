@@ -229,6 +229,46 @@ int rr_reviews_best_cut_dev(rr_reviews* rv, const float* d_queries, int32_t n_qu
                             const int64_t* d_rows, int32_t pool, int64_t row_offset, int64_t max_rows,
                             float* d_best_score, int32_t* d_best_id, void* stream);
 
+/* ------------------------------------------------------------ K5 cross-encoder / query encoder forward */
+
+/* BERT-family encoder on the matrix cores (csrc/rr_ce.hip).  Stands in for
+ *   CrossEncoder.predict(pairs, batch_size=64, show_progress_bar=False)   app/app_product_search.py:277-278, app/test.py:223-225
+ *     (sentence-transformers wraps AutoModelForSequenceClassification; for cross-encoder/ms-marco-MiniLM-L-6-v2 that is
+ *      BertForSequenceClassification: 6 layers, hidden 384, 12 heads, FFN 1536, 512 positions, 1 label)
+ *   SentenceTransformer.encode([query], normalize_embeddings=True)        app/app_product_search.py:250-251, app/test.py:232
+ *     (BAAI/bge-small-en-v1.5: BertModel of the same block shape, 12 layers, CLS pooling; the l2 normalisation is the caller's)
+ * The kernels are built for hidden 384 / 12 heads x 32 / FFN 1536; layer count, vocabulary, positions (<= 512) are free.
+ * Tokenisation (WordPiece) is host work above this ABI (review-recommender_amd/wordpiece.py). */
+typedef struct rr_ce rr_ce;
+typedef struct rr_ce_config {
+    int32_t hidden, n_layers, n_heads, ffn;       /* 384, L, 12, 1536 */
+    int32_t vocab, max_pos, type_vocab;           /* embedding table sizes */
+    int32_t n_labels;                             /* classifier outputs (1 for the reranker); 0 = no pooler / classifier */
+    float ln_eps;                                 /* 1e-12 for BERT */
+} rr_ce_config;
+/* Weights: fp32 host arrays in the layout of a Hugging Face BERT state dict (Linear weights are [out][in]), in this order:
+ *   0 word_embeddings [vocab][H]   1 position_embeddings [max_pos][H]   2 token_type_embeddings [type_vocab][H]
+ *   3 embeddings.LayerNorm.weight  4 embeddings.LayerNorm.bias
+ *   per layer l, 16 tensors from 5 + 16 l: query.weight, query.bias, key.weight, key.bias, value.weight, value.bias,
+ *     attention.output.dense.weight, .bias, attention.output.LayerNorm.weight, .bias,
+ *     intermediate.dense.weight [FFN][H], .bias, output.dense.weight [H][FFN], .bias, output.LayerNorm.weight, .bias
+ *   when n_labels > 0, four more: pooler.dense.weight [H][H], pooler.dense.bias, classifier.weight [n_labels][H], classifier.bias
+ * Linear weights are rounded once to bf16 (nearest even) on the device; everything else stays fp32. */
+int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float* const* h_tensors, int32_t n_tensors, rr_ce** out);
+int rr_ce_destroy(rr_ce* ce);
+#define RR_CE_OUT_LOGITS 0   /* d_out [n_seqs][n_labels]: classifier(tanh(pooler([CLS]))), raw logits (no activation) */
+#define RR_CE_OUT_CLS    1   /* d_out [n_seqs][hidden]: last_hidden_state[:, 0] (CLS pooling of the query encoder) */
+#define RR_CE_OUT_HIDDEN 2   /* d_out [n_tokens][hidden]: last_hidden_state of every token (diagnostic / parity tests) */
+/* Forward over PACKED sequences (no padding is computed): sequence s owns tokens [cu_seqlens[s], cu_seqlens[s+1]);
+ * token / type / position ids are per token (position = index inside its sequence); max_len = longest sequence.
+ * Attention is full inside a sequence (what an all-ones attention mask over the unpadded tokens gives).
+ * Asynchronous on `stream`; all pointers are device pointers. */
+int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_type_ids, const int32_t* d_pos_ids,
+                      const int32_t* d_cu_seqlens, int32_t n_seqs, int64_t n_tokens, int32_t max_len, int32_t mode,
+                      float* d_out, void* stream);
+/* HIP-event time of the last forward pass on this handle (ms). */
+int rr_ce_last_forward_ms(rr_ce* ce, float* out_ms);
+
 /* Development aid (tools/x3w_ablate.py): times ablated variants of the 64-query fp32 batched scan
  * (bit 0: no operand split, bit 1: no B-fragment reads, bit 2: no MFMA, bit 3: no lane swap).
  * Leaves garbage in the scan scratch; never part of a search. */

@@ -21,6 +21,13 @@ class FuseParams(C.Structure):
                 ("bm25_f64", c_i32), ("cand_rank_stride_bytes", c_i64)]
 
 
+class CEConfig(C.Structure):
+    """struct rr_ce_config (include/rr_hip.h)."""
+    _fields_ = [("hidden", c_i32), ("n_layers", c_i32), ("n_heads", c_i32), ("ffn", c_i32),
+                ("vocab", c_i32), ("max_pos", c_i32), ("type_vocab", c_i32), ("n_labels", c_i32),
+                ("ln_eps", c_f32)]
+
+
 # name -> (restype, argtypes); every symbol include/rr_hip.h declares
 PROTOTYPES = {
     "rr_last_error": (C.c_char_p, []),
@@ -58,6 +65,10 @@ PROTOTYPES = {
     "rr_reviews_destroy": (C.c_int, [c_vp]),
     "rr_reviews_best_dev": (C.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "rr_reviews_best_cut_dev": (C.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "rr_ce_create": (C.c_int, [c_i32, P(CEConfig), P(c_vp), c_i32, P(c_vp)]),
+    "rr_ce_destroy": (C.c_int, [c_vp]),
+    "rr_ce_forward_dev": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "rr_ce_last_forward_ms": (C.c_int, [c_vp, P(c_f32)]),
     "rr_index_stream": (C.c_int, [c_vp, P(c_vp)]),
     "rr_index_synchronize": (C.c_int, [c_vp]),
 }

@@ -21,7 +21,7 @@ OBJ_DIR = PKG_DIR / "build"
 LIB_PATH = PKG_DIR / "librr_hip.so"
 BUILD_ID = PKG_DIR / "librr_hip.so.buildid"
 SOURCES = ["rr_api.hip", "rr_dense.hip", "rr_dense_bf16.hip", "rr_dense_x3.hip", "rr_dense_x3w.hip",
-           "rr_dense_flt.hip", "rr_bm25.hip", "rr_fuse.hip", "rr_reviews.hip"]
+           "rr_dense_flt.hip", "rr_bm25.hip", "rr_fuse.hip", "rr_reviews.hip", "rr_ce.hip"]
 # -ffp-contract=off: the BM25 and fusion kernels reproduce numpy's one-rounding-per-
 # operation arithmetic; fused multiply-adds are written out (__builtin_fmaf) where wanted.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]

@@ -1,0 +1,640 @@
+// rr_ce.hip -- K5: BERT-family encoder forward on the gfx950 matrix cores (cross-encoder rerank + query encoder).
+//
+// Replaces `CrossEncoder.predict(pairs, batch_size=64, show_progress_bar=False)` as the reference calls it
+// (app/app_product_search.py:271-282, app/test.py:217-225): a BertForSequenceClassification forward
+// (ms-marco-MiniLM-L-6-v2: 6 layers, hidden 384, 12 heads x 32, FFN 1536, <= 512 tokens, 1 label) over
+// (query, text[:2000]) pairs -- and, with mode RR_CE_OUT_CLS, the SentenceTransformer query encoder of
+// app/app_product_search.py:250-251 (bge-small: the same block shape, 12 layers, CLS pooling).
+//
+// Layout: sequences are PACKED (no padding tokens are ever computed): T = sum of lengths, cu_seqlens[P+1].
+//   residual stream  h32 [T][384] fp32  +  hb [T][384] bf16 (the next GEMM's A operand)
+//   qkv [T][1152] bf16, ctx [T][384] bf16, inter [T][1536] bf16
+// Arithmetic: bf16 MFMA operands (weights rounded once at load, activations at each producer's epilogue),
+// fp32 accumulation, fp32 residual / LayerNorm / softmax / GELU(erf) / pooler / classifier.
+//
+// Kernels (per layer: 4 GEMMs + 1 attention; MFMA-bound, ~4.3 MFLOP per token and layer at 512 tokens):
+//   ce_embed_ln      word + position + type embedding, LayerNorm               (HBM-bound, one wave per token)
+//   ce_gemm<128x128> out = A W^T + b [, GELU] -> bf16      (QKV 384->1152, FFN1 384->1536)
+//   ce_gemm<64x384>  out = LayerNorm(A W^T + b + residual) -> fp32 + bf16      (attention output, FFN2 1536->384):
+//                    a workgroup owns whole rows, so the normalisation is fused into the epilogue
+//   ce_attention     one workgroup per (sequence, head): K and V^T of the head in LDS, S^T = K Q^T on
+//                    v_mfma_f32_16x16x32_bf16 (K = head dim = 32: one MFMA per 16x16 score tile), softmax in
+//                    registers, and the probability tile is fed straight back as the A operand of P V (the
+//                    accumulator-as-operand idiom: no lane movement, no LDS round trip)
+//   ce_head          pooler (tanh) + classifier on the [CLS] rows, fp32
+// GEMM tiles: 32x32x16 bf16 MFMA, K-step 64 through LDS rows padded to 144 B (conflict-free ds_read_b128),
+// next K tile prefetched global -> registers under the MFMAs of the current one.
+#include "rr_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define CE_H 384
+#define CE_HEADS 12
+#define CE_HD 32
+#define CE_FFN 1536
+#define CE_LDK 72          // LDS row of a K tile: 64 bf16 + 8 pad = 144 B
+
+__device__ __forceinline__ unsigned short ce_bf16_bits(float x) {
+    const __bf16 b = (__bf16)x;                      // round to nearest even
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float ce_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ embeddings + LayerNorm
+__global__ __launch_bounds__(256) void ce_embed_ln(const int32_t* __restrict__ tok, const int32_t* __restrict__ typ,
+                                                   const int32_t* __restrict__ pos, int T, int vocab, int n_pos, int n_typ,
+                                                   const float* __restrict__ we, const float* __restrict__ pe,
+                                                   const float* __restrict__ te, const float* __restrict__ g,
+                                                   const float* __restrict__ b, float eps, float* __restrict__ h32,
+                                                   unsigned short* __restrict__ hb) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    int id = tok[t], ty = typ[t], po = pos[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // ids are validated on the host; stay in bounds anyway
+    ty = ty < 0 ? 0 : (ty >= n_typ ? n_typ - 1 : ty);
+    po = po < 0 ? 0 : (po >= n_pos ? n_pos - 1 : po);
+    float x[6];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        x[i] = (we[(int64_t)id * CE_H + c] + te[(int64_t)ty * CE_H + c]) + pe[(int64_t)po * CE_H + c];
+        s += x[i];
+    }
+    const float mean = ce_wave_sum(s) * (1.f / CE_H);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const float d = x[i] - mean; v += d * d; }
+    const float rstd = rsqrtf(ce_wave_sum(v) * (1.f / CE_H) + eps);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        const float y = (x[i] - mean) * rstd * g[c] + b[c];
+        h32[(int64_t)t * CE_H + c] = y;
+        hb[(int64_t)t * CE_H + c] = ce_bf16_bits(y);
+    }
+}
+
+// ------------------------------------------------------------------ GEMM  out[M][N] = A[M][K] W[N][K]^T (+ epilogue)
+#define CE_EPI_BIAS 0        // + bias                      -> bf16
+#define CE_EPI_GELU 1        // gelu_erf(+ bias)            -> bf16
+#define CE_EPI_RES_LN 2      // LayerNorm(+ bias + res32)   -> fp32 (in place over res32) and bf16; needs BN == N
+
+__device__ __forceinline__ float ce_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(256) void ce_gemm(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W,
+                                               const float* __restrict__ bias, int M, int N, int K,
+                                               unsigned short* __restrict__ outb, float* __restrict__ res32,
+                                               const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps) {
+    static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
+    constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MB = TM / 32, NB = TN / 32;
+    constexpr int A_CHUNKS = BM * 8 / 256, W_CHUNKS = BN * 8 / 256;      // 16-B pieces per thread and K tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
+    unsigned short* As = reinterpret_cast<unsigned short*>(ce_smem);           // [BM][CE_LDK]
+    unsigned short* Ws = As + BM * CE_LDK;                                      // [BN][CE_LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * BM;
+    const int col0 = blockIdx.y * BN;
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    u32x4 pa[A_CHUNKS], pw[W_CHUNKS];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, p = c & 7;
+            int64_t row = row0 + r;
+            row = row < M ? row : M - 1;                                   // rows past M are never stored
+            pa[i] = *reinterpret_cast<const u32x4*>(A + row * K + kt * 64 + p * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < W_CHUNKS; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, p = c & 7;
+            pw[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)(col0 + r) * K + kt * 64 + p * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_CHUNKS; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, p = c & 7;
+            *reinterpret_cast<u32x4*>(As + r * CE_LDK + p * 8) = pa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < W_CHUNKS; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, p = c & 7;
+            *reinterpret_cast<u32x4*>(Ws + r * CE_LDK + p * 8) = pw[i];
+        }
+    };
+
+    const int KT = K / 64;
+    load_tile(0);
+    for (int kt = 0; kt < KT; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < KT) load_tile(kt + 1);                                  // in flight under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MB], wf[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(As + (wm * TM + i * 32 + r32) * CE_LDK + ks * 16 + hh * 8);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                wf[j] = *reinterpret_cast<const bf16x8*>(Ws + (wn * TN + j * 32 + r32) * CE_LDK + ks * 16 + hh * 8);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // C layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    if constexpr (EPI != CE_EPI_RES_LN) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int col = col0 + wn * TN + j * 32 + r32;
+                const float bv = bias[col];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = row0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    float v = acc[i][j][e] + bv;
+                    if (EPI == CE_EPI_GELU) v = ce_gelu(v);
+                    if (row < M) outb[row * N + col] = ce_bf16_bits(v);
+                }
+            }
+    } else {
+        // whole rows live in this workgroup (BN == N, WAVES_M == 1): x = acc + bias + residual, two-pass LayerNorm.
+        // Row sums: in-lane over the wave's NB column blocks, a reduce-scatter butterfly over the 32 lanes of a
+        // half (31 shuffles for the lane's MB*16 rows), the four waves' partials through LDS.
+        static_assert(WAVES_M == 1 && MB * 16 == 32, "LayerNorm epilogue: 64-row tile, one wave row");
+        float* red = reinterpret_cast<float*>(ce_smem);                     // [4][BM] partials, then [BM] result
+        float* stat = red + 4 * BM;                                          // [BM] mean, then rstd
+        float bv[NB], gv[NB], be[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = wn * TN + j * 32 + r32;
+            bv[j] = bias[col]; gv[j] = ln_g[col]; be[j] = ln_b[col];
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int64_t rr = row < M ? row : M - 1;
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i][j][e] = (acc[i][j][e] + bv[j]) + res32[rr * N + wn * TN + j * 32 + r32];
+            }
+        float mean_l[MB * 16], rstd_l[MB * 16];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            float v[32];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const float d = pass == 0 ? acc[i][j][e] : acc[i][j][e] - mean_l[i * 16 + e];
+                        s += pass == 0 ? d : d * d;
+                    }
+                    v[i * 16 + e] = s;
+                }
+#pragma unroll
+            for (int si = 0; si < 5; ++si) {
+                const int st = 16 >> si;
+                const bool up = (lane & st) != 0;
+#pragma unroll
+                for (int q = 0; q < st; ++q) {
+                    const float keep = up ? v[q + st] : v[q];
+                    const float send = up ? v[q] : v[q + st];
+                    v[q] = keep + __shfl_xor(send, st, 64);
+                }
+            }
+            // lane (r32, hh) now holds the wave's sum of slot s = r32: block i = s >> 4, e = s & 15
+            {
+                const int s_ = r32, i = s_ >> 4, e = s_ & 15;
+                red[wave * BM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh] = v[0];
+            }
+            __syncthreads();
+            if (tid < BM) {
+                const float tot = (red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid]);
+                stat[tid] = pass == 0 ? tot * (1.f / BN) : rsqrtf(tot * (1.f / BN) + ln_eps);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float sv = stat[i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh];
+                    if (pass == 0) mean_l[i * 16 + e] = sv; else rstd_l[i * 16 + e] = sv;
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (row < M) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int col = wn * TN + j * 32 + r32;
+                        const float y = (acc[i][j][e] - mean_l[i * 16 + e]) * rstd_l[i * 16 + e] * gv[j] + be[j];
+                        res32[row * N + col] = y;
+                        outb[row * N + col] = ce_bf16_bits(y);
+                    }
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------ attention: one workgroup per (sequence, head)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define CE_KS_LD 40         // K rows in LDS: 32 bf16 + 8 pad = 80 B (conflict-free ds_read_b128 over 16 rows)
+
+template <int NT>           // NT = upper bound of 16-key tiles for this launch (multiple of 2)
+__global__ __launch_bounds__(256) void ce_attention(const unsigned short* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                    unsigned short* __restrict__ ctx, float scale) {
+    constexpr int SMAX = NT * 16;
+    constexpr int VT_LD = SMAX + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
+    unsigned short* Ks = reinterpret_cast<unsigned short*>(ce_smem);          // [SMAX][CE_KS_LD]
+    unsigned short* Vt = Ks + SMAX * CE_KS_LD;                                  // [32][VT_LD]   V transposed
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seq = blockIdx.x, head = blockIdx.y;
+    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    const int Spad = (S + 31) & ~31;
+    const int c16 = lane & 15, g = lane >> 4;
+
+    // stage K (row major) and V^T of this head; rows past S are zero
+    for (int c = tid; c < Spad * 4; c += 256) {
+        const int r = c >> 2, p = c & 3;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (r < S) {
+            const unsigned short* base = qkv + (int64_t)(t0 + r) * (3 * CE_H) + head * CE_HD + p * 8;
+            kv = *reinterpret_cast<const u32x4*>(base + CE_H);
+            vv = *reinterpret_cast<const u32x4*>(base + 2 * CE_H);
+        }
+        *reinterpret_cast<u32x4*>(Ks + r * CE_KS_LD + p * 8) = kv;
+        const unsigned short* ve = reinterpret_cast<const unsigned short*>(&vv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(p * 8 + j) * VT_LD + r] = ve[j];
+    }
+    __syncthreads();
+
+    const int n_tiles = Spad >> 4;
+    for (int qb = wave; qb * 16 < S; qb += 4) {
+        // B operand of S^T = K Q^T: lane (q = c16, g) holds Q[q][8g .. 8g+7]
+        int qrow = qb * 16 + c16;
+        qrow = qrow < S ? qrow : S - 1;
+        const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qkv + (int64_t)(t0 + qrow) * (3 * CE_H) + head * CE_HD + g * 8);
+        f32x4_t st[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt < n_tiles) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + c16) * CE_KS_LD + g * 8);
+                f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);   // z[r] = S^T[key 16kt + 4g + r][q = c16]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float s = (kt * 16 + 4 * g + r) < S ? z[r] * scale : -INFINITY;
+                    z[r] = s;
+                    mx = fmaxf(mx, s);
+                }
+                st[kt] = z;
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+            if (kt < n_tiles) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(st[kt][r] - mx);
+                    st[kt][r] = p;
+                    sum += p;
+                }
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        // out[q][d] = sum_k P[q][k] V[k][d]: the probability tiles are the A operand as they sit (lane = q column,
+        // registers = keys); two 16-key tiles form one K = 32 step whose key order is
+        //   element j of lane group g:  j < 4 -> key 32u + 4g + j,   j >= 4 -> key 32u + 16 + 4g + (j - 4)
+        // and V^T is read in that same order.
+        f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NT / 2; ++u)
+            if (2 * u < n_tiles) {
+                bf16x8 pf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pf[r] = (__bf16)st[2 * u][r];
+                    pf[4 + r] = (__bf16)st[2 * u + 1][r];
+                }
+                bf16x8 v0, v1;
+                {
+                    const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(Vt + c16 * VT_LD + 32 * u + 4 * g);
+                    const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(Vt + c16 * VT_LD + 32 * u + 16 + 4 * g);
+                    const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(Vt + (16 + c16) * VT_LD + 32 * u + 4 * g);
+                    const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(Vt + (16 + c16) * VT_LD + 32 * u + 16 + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v0[r] = a0[r]; v0[4 + r] = a1[r]; v1[r] = b0[r]; v1[4 + r] = b1[r]; }
+                }
+                o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, v0, o0, 0, 0, 0);    // o[r] = out[q = 4g + r][d = c16]
+                o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, v1, o1, 0, 0, 0);    //                     [d = 16 + c16]
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qb * 16 + 4 * g + r;
+            const float inv = 1.f / __shfl(sum, 4 * g + r, 64);          // lane 4g + r holds the sum of query column 4g + r
+            if (q < S) {
+                unsigned short* dst = ctx + (int64_t)(t0 + q) * CE_H + head * CE_HD;
+                dst[c16] = ce_bf16_bits(o0[r] * inv);
+                dst[16 + c16] = ce_bf16_bits(o1[r] * inv);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ pooler + classifier on the [CLS] rows (fp32)
+__global__ __launch_bounds__(256) void ce_head(const float* __restrict__ h32, const int32_t* __restrict__ cu,
+                                               const float* __restrict__ wp, const float* __restrict__ bp,
+                                               const float* __restrict__ wc, const float* __restrict__ bc, int n_labels,
+                                               int mode, float* __restrict__ out) {
+    __shared__ float x[CE_H], pooled[CE_H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seq = blockIdx.x;
+    const float* src = h32 + (int64_t)cu[seq] * CE_H;
+    for (int c = tid; c < CE_H; c += 256) x[c] = src[c];
+    __syncthreads();
+    if (mode == 1) {                                       // RR_CE_OUT_CLS: last_hidden_state[:, 0]
+        for (int c = tid; c < CE_H; c += 256) out[(int64_t)seq * CE_H + c] = x[c];
+        return;
+    }
+    for (int j = wave; j < CE_H; j += 4) {                 // pooled[j] = tanh(Wp[j] . x + bp[j])
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s = __builtin_fmaf(wp[(int64_t)j * CE_H + lane + 64 * i], x[lane + 64 * i], s);
+        s = ce_wave_sum(s);
+        if (lane == 0) pooled[j] = tanhf(s + bp[j]);
+    }
+    __syncthreads();
+    for (int l = wave; l < n_labels; l += 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s = __builtin_fmaf(wc[(int64_t)l * CE_H + lane + 64 * i], pooled[lane + 64 * i], s);
+        s = ce_wave_sum(s);
+        if (lane == 0) out[(int64_t)seq * n_labels + l] = s + bc[l];
+    }
+}
+
+__global__ void ce_to_bf16(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = ce_bf16_bits(src[i]);
+}
+
+// ------------------------------------------------------------------ host side
+struct rr_ce_layer {
+    unsigned short *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;      // bf16 [N][K]
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+};
+
+struct rr_ce {
+    int device = 0;
+    rr_ce_config cfg;
+    float *word = nullptr, *pos = nullptr, *type = nullptr, *eln_g = nullptr, *eln_b = nullptr;
+    rr_ce_layer* layers = nullptr;
+    float *wp = nullptr, *bp = nullptr, *wc = nullptr, *bc = nullptr;
+    // activation scratch for `cap` tokens
+    int64_t cap = 0;
+    float* h32 = nullptr;
+    unsigned short *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *inter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::mutex mu;
+};
+
+static int ce_upload_f32(float** dst, const float* src, size_t n) {
+    *dst = nullptr;
+    RR_HIP_TRY(hipMalloc((void**)dst, sizeof(float) * (n ? n : 1)));
+    RR_HIP_TRY(hipMemcpy(*dst, src, sizeof(float) * n, hipMemcpyHostToDevice));
+    return RR_OK;
+}
+
+// fp32 host rows -> bf16 device rows (rounded once, to nearest even, on the device)
+static int ce_upload_bf16(unsigned short* dst, const float* src, size_t n) {
+    float* tmp = nullptr;
+    RR_HIP_TRY(hipMalloc((void**)&tmp, sizeof(float) * n));
+    hipError_t e = hipMemcpy(tmp, src, sizeof(float) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(ce_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, tmp, dst, (int64_t)n);
+        e = hipDeviceSynchronize();
+    }
+    hipFree(tmp);
+    if (e != hipSuccess) { rr_set_error("rr_ce_create: %s", hipGetErrorString(e)); return RR_E_HIP; }
+    return RR_OK;
+}
+
+extern "C" int rr_ce_destroy(rr_ce* ce) {
+    if (!ce) return RR_OK;
+    hipSetDevice(ce->device);
+    hipDeviceSynchronize();
+    hipFree(ce->word); hipFree(ce->pos); hipFree(ce->type); hipFree(ce->eln_g); hipFree(ce->eln_b);
+    if (ce->layers)
+        for (int l = 0; l < ce->cfg.n_layers; ++l) {
+            rr_ce_layer& L = ce->layers[l];
+            hipFree(L.wqkv); hipFree(L.wo); hipFree(L.w1); hipFree(L.w2);
+            hipFree(L.bqkv); hipFree(L.bo); hipFree(L.b1); hipFree(L.b2);
+            hipFree(L.ln1_g); hipFree(L.ln1_b); hipFree(L.ln2_g); hipFree(L.ln2_b);
+        }
+    delete[] ce->layers;
+    hipFree(ce->wp); hipFree(ce->bp); hipFree(ce->wc); hipFree(ce->bc);
+    hipFree(ce->h32); hipFree(ce->hb); hipFree(ce->qkv); hipFree(ce->ctx); hipFree(ce->inter);
+    if (ce->ev0) hipEventDestroy(ce->ev0);
+    if (ce->ev1) hipEventDestroy(ce->ev1);
+    delete ce;
+    return RR_OK;
+}
+
+extern "C" int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float* const* t, int32_t n_tensors,
+                            rr_ce** out) {
+    RR_REQUIRE(out, "rr_ce_create: NULL out");
+    *out = nullptr;
+    RR_REQUIRE(cfg && t, "rr_ce_create: NULL argument");
+    RR_REQUIRE(cfg->hidden == CE_H && cfg->n_heads == CE_HEADS && cfg->ffn == CE_FFN,
+               "rr_ce_create: the kernels are built for hidden 384 / 12 heads x 32 / FFN 1536 (MiniLM-L6, bge-small); "
+               "got hidden %d heads %d ffn %d", cfg->hidden, cfg->n_heads, cfg->ffn);
+    RR_REQUIRE(cfg->n_layers >= 1 && cfg->n_layers <= 48 && cfg->vocab >= 1 && cfg->max_pos >= 1 && cfg->max_pos <= 512 &&
+                   cfg->type_vocab >= 1 && cfg->n_labels >= 0 && cfg->n_labels <= 64 && cfg->ln_eps > 0.f,
+               "rr_ce_create: bad configuration (layers %d vocab %d max_pos %d types %d labels %d)", cfg->n_layers,
+               cfg->vocab, cfg->max_pos, cfg->type_vocab, cfg->n_labels);
+    const int want = 5 + 16 * cfg->n_layers + (cfg->n_labels > 0 ? 4 : 0);
+    RR_REQUIRE(n_tensors == want, "rr_ce_create: %d tensors given, %d expected (include/rr_hip.h lists the order)",
+               n_tensors, want);
+    for (int i = 0; i < n_tensors; ++i) RR_REQUIRE(t[i], "rr_ce_create: tensor %d is NULL", i);
+    RR_HIP_TRY(hipSetDevice(device));
+    rr_ce* ce = new rr_ce();
+    ce->device = device;
+    ce->cfg = *cfg;
+    ce->layers = new rr_ce_layer[cfg->n_layers];
+    const size_t H = CE_H, F = CE_FFN;
+    int rc = RR_OK;
+    auto f32 = [&](float** d, const float* s, size_t n) { if (!rc) rc = ce_upload_f32(d, s, n); };
+    auto b16 = [&](unsigned short* d, const float* s, size_t n) { if (!rc) rc = ce_upload_bf16(d, s, n); };
+    auto alloc16 = [&](unsigned short** d, size_t n) {
+        if (!rc && hipMalloc((void**)d, 2 * n) != hipSuccess) { rr_set_error("rr_ce_create: out of device memory"); rc = RR_E_NOMEM; }
+    };
+    f32(&ce->word, t[0], (size_t)cfg->vocab * H);
+    f32(&ce->pos, t[1], (size_t)cfg->max_pos * H);
+    f32(&ce->type, t[2], (size_t)cfg->type_vocab * H);
+    f32(&ce->eln_g, t[3], H);
+    f32(&ce->eln_b, t[4], H);
+    for (int l = 0; l < cfg->n_layers && !rc; ++l) {
+        const float* const* p = t + 5 + 16 * l;      // q_w q_b k_w k_b v_w v_b o_w o_b ln1_g ln1_b f1_w f1_b f2_w f2_b ln2_g ln2_b
+        rr_ce_layer& L = ce->layers[l];
+        alloc16(&L.wqkv, 3 * H * H);
+        if (!rc) { b16(L.wqkv, p[0], H * H); b16(L.wqkv + H * H, p[2], H * H); b16(L.wqkv + 2 * H * H, p[4], H * H); }
+        if (!rc && hipMalloc((void**)&L.bqkv, sizeof(float) * 3 * H) != hipSuccess) rc = RR_E_NOMEM;
+        if (!rc) {
+            hipMemcpy(L.bqkv, p[1], sizeof(float) * H, hipMemcpyHostToDevice);
+            hipMemcpy(L.bqkv + H, p[3], sizeof(float) * H, hipMemcpyHostToDevice);
+            hipMemcpy(L.bqkv + 2 * H, p[5], sizeof(float) * H, hipMemcpyHostToDevice);
+        }
+        alloc16(&L.wo, H * H);   b16(L.wo, p[6], H * H);   f32(&L.bo, p[7], H);
+        f32(&L.ln1_g, p[8], H);  f32(&L.ln1_b, p[9], H);
+        alloc16(&L.w1, F * H);   b16(L.w1, p[10], F * H);  f32(&L.b1, p[11], F);
+        alloc16(&L.w2, H * F);   b16(L.w2, p[12], H * F);  f32(&L.b2, p[13], H);
+        f32(&L.ln2_g, p[14], H); f32(&L.ln2_b, p[15], H);
+    }
+    if (!rc && cfg->n_labels > 0) {
+        const float* const* p = t + 5 + 16 * cfg->n_layers;
+        f32(&ce->wp, p[0], H * H); f32(&ce->bp, p[1], H);
+        f32(&ce->wc, p[2], (size_t)cfg->n_labels * H); f32(&ce->bc, p[3], (size_t)cfg->n_labels);
+    }
+    if (!rc && (hipEventCreate(&ce->ev0) != hipSuccess || hipEventCreate(&ce->ev1) != hipSuccess)) rc = RR_E_HIP;
+    if (rc) { rr_ce_destroy(ce); return rc; }
+    *out = ce;
+    return RR_OK;
+}
+
+static int ce_reserve(rr_ce* ce, int64_t tokens) {
+    if (tokens <= ce->cap) return RR_OK;
+    RR_HIP_TRY(hipDeviceSynchronize());
+    hipFree(ce->h32); hipFree(ce->hb); hipFree(ce->qkv); hipFree(ce->ctx); hipFree(ce->inter);
+    ce->h32 = nullptr; ce->hb = ce->qkv = ce->ctx = ce->inter = nullptr;
+    ce->cap = 0;
+    const size_t n = (size_t)rr_round_up(tokens, 4096);
+    hipError_t e = hipMalloc((void**)&ce->h32, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->hb, n * CE_H * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->qkv, n * 3 * CE_H * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->ctx, n * CE_H * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->inter, n * CE_FFN * 2);
+    if (e != hipSuccess) { rr_set_error("rr_ce_forward: activation scratch for %lld tokens: %s", (long long)tokens, hipGetErrorString(e)); return RR_E_NOMEM; }
+    ce->cap = (int64_t)n;
+    return RR_OK;
+}
+
+template <int NT>
+static void ce_launch_attention(rr_ce* ce, const int32_t* d_cu, int P, hipStream_t st) {
+    const size_t lds = (size_t)(NT * 16) * CE_KS_LD * 2 + (size_t)32 * (NT * 16 + 8) * 2;
+    hipLaunchKernelGGL((ce_attention<NT>), dim3((unsigned)P, CE_HEADS), dim3(256), lds, st, ce->qkv, d_cu, ce->ctx,
+                       0.17677669529663687f /* 1 / sqrt(32) */);
+}
+
+extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_type_ids,
+                                 const int32_t* d_pos_ids, const int32_t* d_cu_seqlens, int32_t n_seqs,
+                                 int64_t n_tokens, int32_t max_len, int32_t mode, float* d_out, void* stream) {
+    RR_REQUIRE(ce && d_token_ids && d_type_ids && d_pos_ids && d_cu_seqlens && d_out, "rr_ce_forward_dev: NULL argument");
+    RR_REQUIRE(n_seqs >= 1 && n_tokens >= n_seqs && n_tokens < (1ll << 31), "rr_ce_forward_dev: %d sequences / %lld tokens",
+               n_seqs, (long long)n_tokens);
+    RR_REQUIRE(max_len >= 1 && max_len <= ce->cfg.max_pos, "rr_ce_forward_dev: max_len %d outside [1, %d]", max_len,
+               ce->cfg.max_pos);
+    RR_REQUIRE(mode == RR_CE_OUT_LOGITS || mode == RR_CE_OUT_CLS || mode == RR_CE_OUT_HIDDEN, "rr_ce_forward_dev: unknown mode %d", mode);
+    RR_REQUIRE(mode != RR_CE_OUT_LOGITS || ce->cfg.n_labels > 0, "rr_ce_forward_dev: the model was created without a classifier head");
+    std::lock_guard<std::mutex> lk(ce->mu);
+    RR_HIP_TRY(hipSetDevice(ce->device));
+    int rc = ce_reserve(ce, n_tokens);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int T = (int)n_tokens;
+    static bool attr_set = false;
+    if (!attr_set) {
+        // dynamic LDS above 64 KB must be opted into per kernel
+        const int ldsA = (128 + 128) * CE_LDK * 2, ldsB = (64 + 384) * CE_LDK * 2;
+        hipFuncSetAttribute((const void*)ce_gemm<128, 128, 2, 2, CE_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsA);
+        hipFuncSetAttribute((const void*)ce_gemm<128, 128, 2, 2, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsA);
+        hipFuncSetAttribute((const void*)ce_gemm<64, 384, 1, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
+        hipFuncSetAttribute((const void*)ce_attention<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            512 * CE_KS_LD * 2 + 32 * (512 + 8) * 2);
+        hipFuncSetAttribute((const void*)ce_attention<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            256 * CE_KS_LD * 2 + 32 * (256 + 8) * 2);
+        attr_set = true;
+    }
+    hipEventRecord(ce->ev0, st);
+    hipLaunchKernelGGL(ce_embed_ln, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, d_token_ids, d_type_ids, d_pos_ids, T,
+                       ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type, ce->eln_g, ce->eln_b,
+                       ce->cfg.ln_eps, ce->h32, ce->hb);
+    const size_t ldsA = (size_t)(128 + 128) * CE_LDK * 2, ldsB = (size_t)(64 + 384) * CE_LDK * 2;
+    const unsigned gmA = (unsigned)((T + 127) / 128), gmB = (unsigned)((T + 63) / 64);
+    for (int l = 0; l < ce->cfg.n_layers; ++l) {
+        const rr_ce_layer& L = ce->layers[l];
+        hipLaunchKernelGGL((ce_gemm<128, 128, 2, 2, CE_EPI_BIAS>), dim3(gmA, 3 * CE_H / 128), dim3(256), ldsA, st, ce->hb, L.wqkv,
+                           L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
+        if (max_len <= 64) ce_launch_attention<4>(ce, d_cu_seqlens, n_seqs, st);
+        else if (max_len <= 128) ce_launch_attention<8>(ce, d_cu_seqlens, n_seqs, st);
+        else if (max_len <= 256) ce_launch_attention<16>(ce, d_cu_seqlens, n_seqs, st);
+        else ce_launch_attention<32>(ce, d_cu_seqlens, n_seqs, st);
+        hipLaunchKernelGGL((ce_gemm<64, 384, 1, 4, CE_EPI_RES_LN>), dim3(gmB, 1), dim3(256), ldsB, st, ce->ctx, L.wo, L.bo, T, CE_H,
+                           CE_H, ce->hb, ce->h32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
+        hipLaunchKernelGGL((ce_gemm<128, 128, 2, 2, CE_EPI_GELU>), dim3(gmA, CE_FFN / 128), dim3(256), ldsA, st, ce->hb, L.w1, L.b1, T,
+                           CE_FFN, CE_H, ce->inter, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
+        hipLaunchKernelGGL((ce_gemm<64, 384, 1, 4, CE_EPI_RES_LN>), dim3(gmB, 1), dim3(256), ldsB, st, ce->inter, L.w2, L.b2, T, CE_H,
+                           CE_FFN, ce->hb, ce->h32, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
+    }
+    if (mode == RR_CE_OUT_HIDDEN)
+        RR_HIP_TRY(hipMemcpyAsync(d_out, ce->h32, sizeof(float) * (size_t)T * CE_H, hipMemcpyDeviceToDevice, st));
+    else
+        hipLaunchKernelGGL(ce_head, dim3((unsigned)n_seqs), dim3(256), 0, st, ce->h32, d_cu_seqlens, ce->wp, ce->bp, ce->wc, ce->bc,
+                           ce->cfg.n_labels, mode, d_out);
+    hipEventRecord(ce->ev1, st);
+    ce->timed = true;
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+extern "C" int rr_ce_last_forward_ms(rr_ce* ce, float* out_ms) {
+    RR_REQUIRE(ce && out_ms, "rr_ce_last_forward_ms: NULL argument");
+    std::lock_guard<std::mutex> lk(ce->mu);
+    RR_REQUIRE(ce->timed, "rr_ce_last_forward_ms: no forward pass has run yet");
+    RR_HIP_TRY(hipSetDevice(ce->device));
+    RR_HIP_TRY(hipEventSynchronize(ce->ev1));
+    RR_HIP_TRY(hipEventElapsedTime(out_ms, ce->ev0, ce->ev1));
+    return RR_OK;
+}

@@ -83,3 +83,63 @@ def text_corpus(n_docs: int, seed: int, mean_len: int = 12) -> List[str]:
     rng = np.random.default_rng(seed)
     lens = np.maximum(3, rng.poisson(mean_len, n_docs))
     return [" ".join(rng.choice(WORDS, size=int(m))) for m in lens]
+
+
+# ---------------------------------------------------------------- K5: seeded BERT weights
+# Real ms-marco-MiniLM / bge-small weights are not available offline: parity of the
+# encoder kernels is checked on seeded random weights of the same architecture.  The recipe below is plain
+# numpy (identical on every machine); tests/golden/make_k5_golden.py loads the same arrays into
+# transformers' BertForSequenceClassification / BertModel to produce the committed logits.
+def bert_state_dict(seed: int, n_layers: int = 6, hidden: int = 384, ffn: int = 1536, vocab: int = 30522,
+                    max_pos: int = 512, type_vocab: int = 2, n_labels: int = 1, prefix: str = "bert.") -> dict:
+    """Hugging Face BERT state-dict names -> float32 arrays.  Scales are chosen so that activations, attention
+    scores and logits are O(1) (weights N(0, 0.05), LayerNorm gains 1 + N(0, 0.1)): a demanding numerics test,
+    unlike the tiny initializer_range=0.02 default.  n_labels = 0 gives an encoder without pooler / classifier."""
+    rng = np.random.default_rng(seed)
+    nrm = lambda shape, s: (rng.standard_normal(shape, dtype=np.float32) * np.float32(s)).astype(np.float32)
+    sd = {}
+    e = prefix + "embeddings."
+    sd[e + "word_embeddings.weight"] = nrm((vocab, hidden), 0.05)
+    sd[e + "position_embeddings.weight"] = nrm((max_pos, hidden), 0.05)
+    sd[e + "token_type_embeddings.weight"] = nrm((type_vocab, hidden), 0.05)
+    sd[e + "LayerNorm.weight"] = (1.0 + nrm((hidden,), 0.1)).astype(np.float32)
+    sd[e + "LayerNorm.bias"] = nrm((hidden,), 0.05)
+    for l in range(n_layers):
+        p = f"{prefix}encoder.layer.{l}."
+        for name in ("query", "key", "value"):
+            sd[p + f"attention.self.{name}.weight"] = nrm((hidden, hidden), 0.05)
+            sd[p + f"attention.self.{name}.bias"] = nrm((hidden,), 0.02)
+        sd[p + "attention.output.dense.weight"] = nrm((hidden, hidden), 0.05)
+        sd[p + "attention.output.dense.bias"] = nrm((hidden,), 0.02)
+        sd[p + "attention.output.LayerNorm.weight"] = (1.0 + nrm((hidden,), 0.1)).astype(np.float32)
+        sd[p + "attention.output.LayerNorm.bias"] = nrm((hidden,), 0.05)
+        sd[p + "intermediate.dense.weight"] = nrm((ffn, hidden), 0.05)
+        sd[p + "intermediate.dense.bias"] = nrm((ffn,), 0.02)
+        sd[p + "output.dense.weight"] = nrm((hidden, ffn), 0.05)
+        sd[p + "output.dense.bias"] = nrm((hidden,), 0.02)
+        sd[p + "output.LayerNorm.weight"] = (1.0 + nrm((hidden,), 0.1)).astype(np.float32)
+        sd[p + "output.LayerNorm.bias"] = nrm((hidden,), 0.05)
+    if n_labels > 0:
+        sd[prefix + "pooler.dense.weight"] = nrm((hidden, hidden), 0.05)
+        sd[prefix + "pooler.dense.bias"] = nrm((hidden,), 0.02)
+        sd["classifier.weight"] = nrm((n_labels, hidden), 0.05)
+        sd["classifier.bias"] = nrm((n_labels,), 0.02)
+    return sd
+
+
+def token_pairs(n_pairs: int, seed: int, vocab: int = 30522, min_len: int = 4, max_len: int = 512,
+                query_len=(3, 12)):
+    """Synthetic [CLS] query [SEP] text [SEP] id sequences: list of (token_ids, type_ids) int32 arrays with
+    total lengths spread over [min_len, max_len] (ids 999.. avoid the special-token range)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_pairs):
+        total = int(rng.integers(min_len, max_len + 1))
+        ql = int(min(rng.integers(query_len[0], query_len[1] + 1), max(total - 3, 1)))
+        tl = max(total - 3 - ql, 0)
+        q = rng.integers(999, vocab, ql)
+        t = rng.integers(999, vocab, tl)
+        ids = np.concatenate([[101], q, [102], t, [102]]).astype(np.int32)
+        typ = np.concatenate([np.zeros(ql + 2), np.ones(tl + 1)]).astype(np.int32)
+        out.append((ids, typ))
+    return out

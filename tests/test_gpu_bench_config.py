@@ -40,7 +40,7 @@ def shard():
 def test_device_built_csr_invariants(shard):
     sh, a = shard
     nnz = sh.stats["nnz"]
-    assert 35 * DOCS < nnz < 41 * DOCS                       # ~40 tokens/doc, a few repeats inside a doc
+    assert 30 * DOCS < nnz < 41 * DOCS                       # ~40 tokens/doc; Zipf repeats inside a doc merge into tf
     assert a["post_indptr"][-1] == nnz == a["doc_indptr"][-1]
     # ascending docs per term / ascending terms per doc: what the binary searches of rr_bm25_at rely on
     d = np.diff(a["post_docs"].astype(np.int64))
