@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""K5 timing: cross-encoder forward over packed pairs (BASELINE config 5 shape: pairs of <= 512 tokens).
+Prints one JSON line with pairs/s, tokens/s and the bf16 MFMA roofline fraction (algorithmic FLOPs of the
+GEMMs + attention / HIP-event time of the forward / 2.5 PFLOP/s)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=256)
+    ap.add_argument("--len", type=int, default=512, help="tokens per pair (fixed), or 0 for lengths uniform in [64, 512]")
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--reps", type=int, default=5)
+    a = ap.parse_args()
+    from review_recommender_amd import synth
+    from review_recommender_amd.cross_encoder import CrossEncoder
+    sd = synth.bert_state_dict(1, n_layers=a.layers, n_labels=1)
+    ce = CrossEncoder(sd)
+    if a.len:
+        seqs = synth.token_pairs(a.pairs, 2, min_len=a.len, max_len=a.len)
+    else:
+        seqs = synth.token_pairs(a.pairs, 2, min_len=64, max_len=512)
+    lens = np.array([len(s[0]) for s in seqs], dtype=np.float64)
+    T = lens.sum()
+    flops = a.layers * (T * 2.0 * 384 * (1152 + 384 + 2 * 1536) + (4.0 * 384 * lens * lens).sum())
+    ce.predict_ids(seqs)
+    ms = []
+    for _ in range(a.reps):
+        ce.predict_ids(seqs)
+        ms.append(ce.model.last_forward_ms())
+    t = float(np.median(ms)) * 1e-3
+    print(json.dumps({"pairs": a.pairs, "tokens": int(T), "layers": a.layers, "forward_ms": round(t * 1e3, 3),
+                      "pairs_per_s": round(a.pairs / t, 1), "tokens_per_s": round(T / t, 1),
+                      "algorithmic_tflop": round(flops / 1e12, 4), "achieved_tflops": round(flops / t / 1e12, 2),
+                      "roofline": {"bound": "mfma", "achieved": round(flops / t / 1e12, 2), "peak": 2500.0,
+                                   "unit": "TFLOP/s", "frac": round(flops / t / 2.5e15, 4)}}))
+
+
+if __name__ == "__main__":
+    main()
