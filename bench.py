@@ -284,6 +284,7 @@ def main():
 
     if rank == 0:
         avg_ms = total_ms / max(launches, 1)
+        bytes_per_launch = n_local * DIM * info["elem_bytes"]      # what the batched scan streams once per launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         qpl, terms_per_dim = info["queries_per_launch"], info["mfma_terms"]
         # HBM traffic per launch from the PMC passes kept in profiles/ (FETCH_SIZE / WRITE_SIZE collected and
@@ -292,7 +293,7 @@ def main():
         traffic = None
         for tag in ("r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_scan_b{qpl}_10M.json")
-            if os.path.exists(pmc) and args.dtype == "f32":
+            if os.path.exists(pmc) and args.dtype == "f32" and info["elem_bytes"] == 4:
                 with open(pmc) as f:
                     m = json.load(f)
                 traffic = int(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"] * bytes_per_launch)
@@ -357,10 +358,11 @@ def _scan_info(index):
     from review_recommender_amd import _lib
     out = (C.c_int32 * 8)()
     _lib.check(_lib.load().rr_index_last_scan_info(index.handle, out), "rr_index_last_scan_info")
-    kid, variant, qpl, terms = out[0], out[1], out[2], out[3]
+    kid, variant, qpl, terms, ebytes = out[0], out[1], out[2], out[3], out[4]
     name = _KERNELS.get(kid, "unknown").replace("NQ2", str(variant)).replace("NQT", str(variant)).replace("NB", str(variant))
-    return {"kernel": f"{name},{'bf16' if index.dtype == 'bf16' else 'f32'}", "queries_per_launch": int(qpl),
-            "mfma_terms": int(terms)}
+    stream = "bf16 rows" if index.dtype == "bf16" else ("bf16 filter plane of the fp32 rows" if ebytes == 2 else "fp32 rows")
+    return {"kernel": f"{name} over {stream}", "queries_per_launch": int(qpl), "mfma_terms": int(terms),
+            "elem_bytes": int(ebytes) or (2 if index.dtype == "bf16" else 4)}
 
 
 if __name__ == "__main__":

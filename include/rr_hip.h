@@ -99,7 +99,8 @@ int rr_index_scan_stats(rr_index* ix, double* out_total_ms, int64_t* out_launche
 /* Which scan kernel the last scan launch on this handle ran: out8[0] = 1 rr_scan_f32, 2 rr_scan_bf16,
  * 3 rr_scan_mfma_x3, 4 rr_scan_x3w, 5 rr_scan_flt, 6 rr_scan_mfma_f32, 7 rr_scan_mfma_bf16; [1] = its template
  * variant (query tiles / query slots); [2] = queries in that launch; [3] = bf16 MFMA terms per dimension
- * (0: not a bf16 matrix-core kernel).  bench.py names the roofline kernel from this. */
+ * (0: not a bf16 matrix-core kernel); [4] = bytes per matrix element the scan streamed (2 = bf16 rows or the bf16
+ * filter plane, 4 = fp32 rows).  bench.py names the roofline kernel and its algorithmic bytes from this. */
 int rr_index_last_scan_info(rr_index* ix, int32_t* out8);
 /* Path taken by the last top-pool selection for its first query: out16[0] = 2: M-tile maxima + rescoring
  * (the batched paths), 1: stored scores through the LDS-resident 3-level selection, 0: generic radix
@@ -110,6 +111,12 @@ int rr_index_select_trace(rr_index* ix, int32_t* out16);
  * M-tile maxima and the candidate M-tiles are rescored (select trace out16[0] == 2), with the
  * stored-score pass as per-query fallback.  RR_SCAN_MODE_STORED: always the single pass that
  * stores every score.  Both return identical rows and scores; tests compare them. */
+/* The bf16 filter plane of an fp32 index (default on): the batched filter scan (5..128 queries per launch) streams a
+ * once-rounded bf16 copy of the matrix (n_rows x 384 x 2 bytes of extra HBM, built lazily at the first batched search
+ * and dropped by any write to the matrix) instead of the fp32 rows -- half the bytes per launch for the same approximate
+ * scores and the same error bound -- and candidates are rescored on the fp32 rows exactly as before: identical answers.
+ * enable = 0 frees the plane and scans the fp32 rows.  Environment RR_NO_SHADOW=1 does the same process-wide. */
+int rr_index_set_shadow(rr_index* ix, int32_t enable);
 #define RR_SCAN_MODE_DEFAULT 0
 #define RR_SCAN_MODE_STORED 1
 int rr_index_set_scan_mode(rr_index* ix, int32_t mode);

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "rr_index_scan_stats": (C.c_int, [c_vp, P(c_f64), P(c_i64)]),
     "rr_index_last_scan_info": (C.c_int, [c_vp, P(c_i32)]),
     "rr_index_select_trace": (C.c_int, [c_vp, P(c_i32)]),
+    "rr_index_set_shadow": (C.c_int, [c_vp, c_i32]),
     "rr_index_set_scan_mode": (C.c_int, [c_vp, c_i32]),
     "rr_debug_scan_x3w": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
     "rr_debug_scan_flt": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),

@@ -105,7 +105,7 @@ extern "C" int rr_index_upload_rows(rr_index* ix, int64_t first_row, int64_t n_r
     int rc = rr_alloc_matrix(ix);
     if (rc) return rc;
     const size_t es = rr_elem_size(ix->dtype);
-    ix->norm_bound = -1.f;
+    rr_matrix_written(ix);
     char* dst = (char*)ix->d_matrix + (size_t)first_row * ix->dim_pad * es;
     if (n_rows)
         RR_HIP_TRY(hipMemcpy2DAsync(dst, es * ix->dim_pad, h_rows, es * ix->dim, es * ix->dim, (size_t)n_rows,
@@ -125,7 +125,7 @@ extern "C" int rr_index_upload_rows_f32(rr_index* ix, int64_t first_row, int64_t
     RR_REQUIRE(ix->owns_matrix || !ix->d_matrix, "rr_index_upload_rows_f32: matrix is caller-owned");
     int rc = rr_alloc_matrix(ix);
     if (rc || n_rows == 0) return rc;
-    ix->norm_bound = -1.f;   // any write to the matrix (either storage dtype) invalidates the cached row-norm bound
+    rr_matrix_written(ix);   // any write to the matrix (either storage dtype) invalidates the cached bound and filter plane
     if (ix->dtype == RR_DTYPE_F32) {
         char* dst = (char*)ix->d_matrix + (size_t)first_row * ix->dim_pad * 4;
         RR_HIP_TRY(hipMemcpy2DAsync(dst, 4 * (size_t)ix->dim_pad, h_rows, 4 * (size_t)ix->dim, 4 * (size_t)ix->dim,
@@ -152,7 +152,7 @@ extern "C" int rr_index_adopt_device(rr_index* ix, const void* d_matrix) {
     RR_HIP_TRY(hipSetDevice(ix->device));
     if (ix->d_matrix && ix->owns_matrix) hipFree(ix->d_matrix);
     ix->d_matrix = const_cast<void*>(d_matrix);
-    ix->norm_bound = -1.f;
+    rr_matrix_written(ix);
     ix->owns_matrix = false;
     return RR_OK;
 }
@@ -186,7 +186,7 @@ extern "C" int rr_index_destroy(rr_index* ix) {
     if (ix->d_matrix && ix->owns_matrix) hipFree(ix->d_matrix);
     hipFree(ix->d_n_reviews); hipFree(ix->d_avg_stars); hipFree(ix->d_log1p_n);
     hipFree(ix->d_sims); hipFree(ix->d_gmax); hipFree(ix->d_smax); hipFree(ix->d_sel_trace); hipFree(ix->d_qplanes); hipFree(ix->d_x3); hipFree(ix->d_q);
-    hipFree(ix->d_rows_out); hipFree(ix->d_scores_out);
+    hipFree(ix->d_rows_out); hipFree(ix->d_scores_out); hipFree(ix->d_shadow);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);
     if (ix->ev_done) hipEventDestroy(ix->ev_done);

@@ -54,7 +54,13 @@ struct rr_index {
     float* d_q = nullptr;        // staged queries [RR_MAX_BATCH][dim_pad]
     float norm_bound = -1.f;     // upper bound of the largest row norm; < 0: not computed (any write to the matrix resets it)
     float delta_bound = 0.f;     // ... and of the largest ||row - bf16(row)||
-    int32_t last_scan[4] = {0, 0, 0, 0};   // kernel id, template variant, queries in the launch, bf16 MFMA terms per dim
+    int32_t last_scan[5] = {0, 0, 0, 0, 0};   // kernel id, template variant, queries in the launch, bf16 MFMA terms per dim, bytes per scanned element
+    // bf16 filter plane of an fp32 matrix (rr_dense_flt.hip): every element rounded once to nearest even.  The batched
+    // filter scan reads it instead of the fp32 rows (half the bytes per launch, the same approximate scores: the scan
+    // rounds to bf16 anyway); candidates are rescored on the fp32 rows.  Built lazily, dropped by any write to the matrix.
+    unsigned short* d_shadow = nullptr;
+    bool shadow_valid = false;
+    int32_t use_shadow = 1;
     int32_t scan_mode = 0;       // RR_SCAN_MODE_* (rr_index_set_scan_mode)
     void* d_x3 = nullptr;        // two-pass selection scratch of the split-operand scan (rr_x3_scratch)
     void* d_qplanes = nullptr;   // [3][64][384] bf16: one launch's queries split in three bf16 terms

@@ -32,8 +32,14 @@ struct rr_scan_geom {
 rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks);
 // Which kernel a scan launch ran (rr_index_last_scan_info): 1 rr_scan_f32, 2 rr_scan_bf16, 3 rr_scan_mfma_x3,
 // 4 rr_scan_x3w, 5 rr_scan_flt, 6 rr_scan_mfma_f32, 7 rr_scan_mfma_bf16; terms = bf16 MFMA terms per dimension.
-static inline void rr_scan_note(rr_index* ix, int kernel, int variant, int nq, int terms) {
+static inline void rr_scan_note(rr_index* ix, int kernel, int variant, int nq, int terms, int elem_bytes = 0) {
     ix->last_scan[0] = kernel; ix->last_scan[1] = variant; ix->last_scan[2] = nq; ix->last_scan[3] = terms;
+    ix->last_scan[4] = elem_bytes ? elem_bytes : (ix->dtype == RR_DTYPE_BF16 ? 2 : 4);
+}
+// any write to the matrix: the cached row-norm bound and the bf16 filter plane no longer describe it
+static inline void rr_matrix_written(rr_index* ix) {
+    ix->norm_bound = -1.f;
+    ix->shadow_valid = false;
 }
 // HIP-event pair around a scan launch (rr_index_scan_stats).
 int rr_scan_events_begin(rr_index* ix, hipStream_t st);

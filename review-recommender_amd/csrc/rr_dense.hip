@@ -1306,7 +1306,21 @@ extern "C" int rr_index_last_scan_ms(rr_index* ix, float* out_ms) {
 extern "C" int rr_index_last_scan_info(rr_index* ix, int32_t* out8) {
     RR_REQUIRE(ix && out8, "rr_index_last_scan_info: NULL argument");
     std::lock_guard<std::mutex> lk(ix->mu);
-    for (int i = 0; i < 8; ++i) out8[i] = i < 4 ? ix->last_scan[i] : 0;
+    for (int i = 0; i < 8; ++i) out8[i] = i < 5 ? ix->last_scan[i] : 0;
+    return RR_OK;
+}
+
+extern "C" int rr_index_set_shadow(rr_index* ix, int32_t enable) {
+    RR_REQUIRE(ix != nullptr, "null index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->use_shadow = enable ? 1 : 0;
+    if (!enable && ix->d_shadow) {
+        RR_HIP_TRY(hipSetDevice(ix->device));
+        RR_HIP_TRY(hipDeviceSynchronize());
+        hipFree(ix->d_shadow);
+        ix->d_shadow = nullptr;
+        ix->shadow_valid = false;
+    }
     return RR_OK;
 }
 
@@ -1359,7 +1373,7 @@ extern "C" int rr_index_l2_normalize(rr_index* ix, float eps) {
                "rr_index_l2_normalize: a bf16 index is normalised in fp32 before rounding (rr_index_upload_rows_f32)");
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
-    ix->norm_bound = -1.f;
+    rr_matrix_written(ix);
     const int rows_per_block = 4;
     const unsigned grid = (unsigned)((ix->n_rows + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(rr_l2norm_f32, dim3(grid), dim3(64 * rows_per_block), 0, ix->stream,

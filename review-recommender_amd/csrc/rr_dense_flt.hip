@@ -32,6 +32,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define RR_FLT_QSTRIDE 49   // 16-B units per query in LDS: 48 + 1 pad (eight consecutive queries, eight bank groups)
 
@@ -470,24 +471,54 @@ static rr_scan_geom rr_flt_geom(rr_index* ix) {
     return G;
 }
 
-template <int NQ2, bool A_BF16>
-static int rr_dense_chunk_flt_t(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
+// fp32 rows -> the bf16 filter plane (round to nearest even, the rounding rr_row_norm_max<false> bounds)
+__global__ __launch_bounds__(256) void rr_shadow_from_f32(const f32x4* __restrict__ src, u32x2* __restrict__ dst, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 x = __builtin_nontemporal_load(src + i);
+    const bf16x2 lo = bf16x2{(__bf16)x.x, (__bf16)x.y}, hi = bf16x2{(__bf16)x.z, (__bf16)x.w};
+    dst[i] = u32x2{__builtin_bit_cast(unsigned int, lo), __builtin_bit_cast(unsigned int, hi)};
+}
+
+static int rr_flt_ensure_shadow(rr_index* ix, hipStream_t st) {
+    if (ix->shadow_valid) return RR_OK;
+    const size_t bytes = (size_t)ix->n_rows * 384 * 2;
+    if (!ix->d_shadow) {
+        const hipError_t e = hipMalloc((void**)&ix->d_shadow, bytes);
+        if (e != hipSuccess) {          // no room for the plane: scan the fp32 rows (correct, twice the bytes)
+            (void)hipGetLastError();
+            ix->use_shadow = 0;
+            return RR_OK;
+        }
+    }
+    const int64_t n4 = ix->n_rows * 96;
+    hipLaunchKernelGGL(rr_shadow_from_f32, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st,
+                       reinterpret_cast<const f32x4*>(ix->d_matrix), reinterpret_cast<u32x2*>(ix->d_shadow), n4);
+    RR_HIP_TRY(hipGetLastError());
+    ix->shadow_valid = true;
+    return RR_OK;
+}
+
+// SCAN_BF16: element type of the matrix the filter scan streams (the index's own bf16 rows, or the bf16 plane of an
+// fp32 index); ROWS_BF16: storage of the index, i.e. of the rows the candidates are rescored on.
+template <int NQ2, bool SCAN_BF16, bool ROWS_BF16>
+static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float* d_q, int nq, int pool, int64_t* d_rows,
                                 float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
-    const rr_scan_geom G = rr_flt_geom<NQ2, A_BF16>(ix);
+    const rr_scan_geom G = rr_flt_geom<NQ2, SCAN_BF16>(ix);
     unsigned short* plane = reinterpret_cast<unsigned short*>(ix->d_qplanes);
     const rr_x3_scratch X = rr_x3_scratch_of(ix);
     hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, X.eps, bounds,
-                       A_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL);
+                       SCAN_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     const int slot = rr_scan_events_begin(ix, st);
-    rr_scan_note(ix, 5, NQ2, nq, 1);
-    hipLaunchKernelGGL((rr_scan_flt<NQ2, A_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
+    rr_scan_note(ix, 5, NQ2, nq, 1, SCAN_BF16 ? 2 : 4);
+    hipLaunchKernelGGL((rr_scan_flt<NQ2, SCAN_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
                        reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax, X.eps, nq);
     rr_scan_events_end(ix, slot, st);
     rr_launch_select_mtiles(ix, G, nq, pool, st, X.eps);
-    hipLaunchKernelGGL((rr_rescore_chain<A_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
+    hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
                        X.mtiles, X.count, X.fb, X.sc);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st);
     RR_HIP_TRY(hipGetLastError());
@@ -509,19 +540,33 @@ int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t
     // keep the answer bitwise equal to what a large index (or the unsharded one) gives through rescoring.
     if ((ix->n_rows + 63) / 64 < 8 * (int64_t)pool) return RR_FLT_SMALL;
     rr_flt_bounds nb;
-    const int rc = rr_flt_get_bounds(ix, st, &nb);
+    int rc = rr_flt_get_bounds(ix, st, &nb);
     if (rc != RR_OK) return rc;
     if (!(nb.row_norm < 3.0e18f))     // no usable bound (inf / NaN rows, or squares that overflow): exact scans, 64 at a time
         return RR_FLT_NO_BOUND;
     const bool b = ix->dtype == RR_DTYPE_BF16;
+    static const bool no_shadow = getenv("RR_NO_SHADOW") != nullptr;
+    if (!b && ix->use_shadow && !no_shadow) {
+        // fp32 storage: the scan streams the bf16 filter plane (half the bytes per launch; the approximate scores
+        // and their bound are those of the on-the-fly rounding), the candidates are rescored on the fp32 rows
+        rc = rr_flt_ensure_shadow(ix, st);
+        if (rc != RR_OK) return rc;
+        if (ix->shadow_valid) {
+            const void* sm = ix->d_shadow;
+            if (nq <= 32) return rr_dense_chunk_flt_t<1, true, false>(ix, sm, d_q, nq, pool, d_rows, d_scores, nb, st);
+            if (nq <= 64) return rr_dense_chunk_flt_t<2, true, false>(ix, sm, d_q, nq, pool, d_rows, d_scores, nb, st);
+            return rr_dense_chunk_flt_t<4, true, false>(ix, sm, d_q, nq, pool, d_rows, d_scores, nb, st);
+        }
+    }
+    const void* m = ix->d_matrix;
     if (nq <= 32)
-        return b ? rr_dense_chunk_flt_t<1, true>(ix, d_q, nq, pool, d_rows, d_scores, nb, st)
-                 : rr_dense_chunk_flt_t<1, false>(ix, d_q, nq, pool, d_rows, d_scores, nb, st);
+        return b ? rr_dense_chunk_flt_t<1, true, true>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st)
+                 : rr_dense_chunk_flt_t<1, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st);
     if (nq <= 64)
-        return b ? rr_dense_chunk_flt_t<2, true>(ix, d_q, nq, pool, d_rows, d_scores, nb, st)
-                 : rr_dense_chunk_flt_t<2, false>(ix, d_q, nq, pool, d_rows, d_scores, nb, st);
-    return b ? rr_dense_chunk_flt_t<4, true>(ix, d_q, nq, pool, d_rows, d_scores, nb, st)
-             : rr_dense_chunk_flt_t<4, false>(ix, d_q, nq, pool, d_rows, d_scores, nb, st);
+        return b ? rr_dense_chunk_flt_t<2, true, true>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st)
+                 : rr_dense_chunk_flt_t<2, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st);
+    return b ? rr_dense_chunk_flt_t<4, true, true>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st)
+             : rr_dense_chunk_flt_t<4, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st);
 }
 
 // Timing-only ablations of the 128-query fp32 filter scan (tools/flt_ablate.py).  Garbage in the scratch afterwards.

@@ -77,7 +77,18 @@ def test_shard_scores_with_corpus_wide_statistics():
     assert np.array_equal(shard.get_scores_ids(q[0]), ora.get_scores(q[0])[3000:7000])
 
 
-def test_too_many_query_tokens_is_an_error():
-    dev = BM25Corpus.from_corpus(CORPUS).to_device()
-    with pytest.raises(ValueError):
-        dev.scores_at_ids([np.zeros(65, dtype=np.int32)], np.zeros((1, 3), dtype=np.int64))
+def test_queries_of_any_length_are_scored_in_64_token_passes():
+    """get_scores has no token limit; the candidate kernel stages 64 tokens per pass and keeps one running
+    float64 sum per candidate, so the additions stay in token order across passes (bit-exact)."""
+    n, vocab = 20_000, 500
+    ip, terms, tf, dl = synth.bm25_forward_csr(n, vocab, 30, 5)
+    corpus = BM25Corpus(ip, terms, tf, dl, vocab)
+    dev = corpus.to_device()
+    ora = csr_oracle(corpus)
+    rng = np.random.default_rng(6)
+    for n_tok in (64, 65, 128, 150, 333):
+        q = rng.integers(-1, vocab, n_tok).astype(np.int32)        # includes unknown tokens (-1) and repeats
+        rows = rng.integers(0, n, (1, 150)).astype(np.int64)
+        want = ora.get_scores(q.tolist())[rows[0]].astype(np.float32)
+        for mode in ("forward", "postings"):
+            assert np.array_equal(dev.scores_at_ids([q], rows, mode)[0], want), (n_tok, mode)

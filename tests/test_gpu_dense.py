@@ -423,3 +423,47 @@ def test_filter_scan_ragged_tail_and_ties(batch):
     dup = [5] + list(range(n - 50, n - 5))
     assert rows_all[7][:46].tolist() == sorted(dup)
     ix.close()
+
+
+def _scan_info(ix):
+    import ctypes as C
+    from review_recommender_amd import _lib
+    out = (C.c_int32 * 8)()
+    _lib.check(_lib.load().rr_index_last_scan_info(ix.handle, out), "rr_index_last_scan_info")
+    return tuple(out)
+
+
+def test_bf16_filter_plane_of_an_fp32_index_gives_bitwise_the_same_answers(hip):
+    """An fp32 index scans a once-rounded bf16 copy of its rows in the batched filter path (half the bytes per
+    launch) and rescores candidates on the fp32 rows: the answers must equal, bit for bit, those of the scan
+    over the fp32 rows themselves (rr_index_set_shadow(0)) and those of the single-query scan; a write to the
+    matrix drops the plane."""
+    from review_recommender_amd import _lib
+    n = 200_000
+    V = synth.unit_rows(n, 384, 91)
+    V[500:530] = V[7]
+    Q = synth.unit_rows(130, 384, 92)
+    Q[4] = V[7]
+    ix = ProductIndex(V)
+    rows_s, sc_s = ix.dense_topk(Q, 150)
+    info = _scan_info(ix)
+    assert info[0] == 5 and info[4] == 2, "the batched scan must have streamed the bf16 plane"
+    _lib.check(hip.rr_index_set_shadow(ix.handle, 0), "set_shadow")
+    rows_f, sc_f = ix.dense_topk(Q, 150)
+    assert _scan_info(ix)[4] == 4
+    assert np.array_equal(rows_s, rows_f) and np.array_equal(sc_s.view(np.uint32), sc_f.view(np.uint32))
+    _lib.check(hip.rr_index_set_shadow(ix.handle, 1), "set_shadow")
+    for i in (0, 4, 77, 129):
+        r1, s1 = ix.dense_topk(Q[i:i + 1], 150)
+        assert np.array_equal(r1[0], rows_s[i]) and np.array_equal(s1[0].view(np.uint32), sc_s[i].view(np.uint32))
+    check_against_oracle(V, Q[:5], 150, index=ix)
+    # new rows over the old ones: the plane (and the row-norm bound) must follow
+    V2 = synth.unit_rows(n, 384, 93)
+    _lib.check(hip.rr_index_upload_rows(ix.handle, 0, n, _lib.ptr(V2)), "upload")
+    rows_b, sc_b = ix.dense_topk(Q[:40], 150)
+    assert _scan_info(ix)[4] == 2
+    for i in (0, 13, 39):
+        r1, s1 = ix.dense_topk(Q[i:i + 1], 150)
+        assert np.array_equal(r1[0], rows_b[i]) and np.array_equal(s1[0].view(np.uint32), sc_b[i].view(np.uint32))
+    check_against_oracle(V2, Q[:3], 150, index=ix)
+    ix.close()

@@ -260,10 +260,12 @@ def test_one_engine_shared_by_threads(world):
             assert got[i][0] == want[i][0] and np.array_equal(got[i][1], want[i][1])
 
 
-def test_cli_without_bm25_artefact_blends_in_float64_from_the_second_term(world):
+def test_cli_without_bm25_artefact_blends_in_float64_from_the_second_term(hip, world):
     """in the CLI, `cand["_bm25"] = 0.0` (no artefact, app/test.py:252) is a float64 column, so
-    the blend is float64 from the second term on even when the float32 rerank column is active; the
-    fusion kernel must follow (rr_fuse_params.bm25_f64) and the frame's dtypes too."""
+    the blend is float64 from the second term on even when the float32 rerank column is active.  The fusion
+    kernel fed the oracle's pool must reproduce every column bit for bit (rr_fuse_params.bm25_f64); end to end
+    (the dense scores then come from K1, whose summation order is not BLAS's) the bar is 1e-5 and the frame's
+    dtypes must be the reference's."""
     ce = FakeCrossEncoder()
     engine = SearchEngine(world["meta"], world["V"], None, cross_encoder=ce, normalize=False, flavour="cli")
     cfg = dict(k=100, rerank_k=60, w_dense=0.37, w_bm25=0.21, w_rerank=0.33, w_prior=0.17, w_best=0.0,
@@ -282,7 +284,22 @@ def test_cli_without_bm25_artefact_blends_in_float64_from_the_second_term(world)
         g, w = got.set_index("sku")["_final"], want.set_index("sku")["_final"]
         common = [s_ for s_ in g.index if s_ in w.index]
         assert len(common) >= cfg["k"] - 2
-        assert np.array_equal(g.loc[common].values, w.loc[common].values)        # bit-exact finals
+        np.testing.assert_allclose(g.loc[common].values, w.loc[common].values, atol=TOL, rtol=0)
+        # K3 alone on the oracle's pool: bit-exact, and NOT what the float32-first order gives
+        pool = len(cand)
+        rows = cand["_row"].values.astype(np.int64)[None, :]
+        dense = np.ascontiguousarray((world["V"] @ qvec)[rows[0]].astype(np.float32)[None, :])
+        rr = np.zeros((1, pool), dtype=np.float32)
+        texts = cand["agg_text"].astype(str).str.slice(0, 2000).tolist()[:cfg["rerank_k"]]
+        rr[0, :cfg["rerank_k"]] = ce.predict([(query, t) for t in texts])
+        gate = np.ascontiguousarray(cand["_gate"].values.astype(np.float32)[None, :])
+        wts = FusionWeights(cfg["w_dense"], cfg["w_bm25"], cfg["w_rerank"], cfg["w_prior"], cfg["w_best"],
+                            cfg["prior_C"], cfg["min_reviews"], cfg["gate_penalty"], apply_trust=False)
+        params = HybridSearcher.make_params(wts, cfg["k"], pool, pool, cfg["rerank_k"], bm25_f64=True)
+        _, cols, _ = fuse_host(hip, engine.index, params, rows, dense, None, rr, gate)
+        for j, c in enumerate(COLUMN_NAMES):
+            if c in cand.columns:
+                assert np.array_equal(cols[0, j], cand[c].values.astype(np.float64), equal_nan=True), f"column {c} differs"
         s32 = np.float32(cfg["w_dense"]) * cand["_dense"].values + np.float32(cfg["w_rerank"]) * cand["_rerank"].values
         alt = (s32.astype(np.float64) + cfg["w_prior"] * cand["_prior"].values).astype(np.float32)
         differs += int(np.any(alt != cand["_final"].values))
