@@ -15,7 +15,7 @@
 // Kernels (per layer: 4 GEMMs + 1 attention; MFMA-bound, ~4.3 MFLOP per token and layer at 512 tokens):
 //   ce_embed_ln      word + position + type embedding, LayerNorm               (HBM-bound, one wave per token)
 //   ce_gemm<128x128> out = A W^T + b [, GELU] -> bf16      (QKV 384->1152, FFN1 384->1536)
-//   ce_gemm<64x384>  out = LayerNorm(A W^T + b + residual) -> fp32 + bf16      (attention output, FFN2 1536->384):
+//   ce_gemm<128x384> out = LayerNorm(A W^T + b + residual) -> fp32 + bf16      (attention output, FFN2 1536->384):
 //                    a workgroup owns whole rows, so the normalisation is fused into the epilogue
 //   ce_attention     one workgroup per (sequence, head): K and V^T of the head in LDS, S^T = K Q^T on
 //                    v_mfma_f32_16x16x32_bf16 (K = head dim = 32: one MFMA per 16x16 score tile), softmax in
@@ -89,24 +89,45 @@ __global__ __launch_bounds__(256) void ce_embed_ln(const int32_t* __restrict__ t
 #define CE_EPI_GELU 1        // gelu_erf(+ bias)            -> bf16
 #define CE_EPI_RES_LN 2      // LayerNorm(+ bias + res32)   -> fp32 (in place over res32) and bf16; needs BN == N
 
-__device__ __forceinline__ float ce_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// gelu(x) = x/2 (1 + erf(x / sqrt 2)), erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
+// rounding of the result): 1 - (a1 t + .. + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z = |x| / sqrt 2; one v_rcp, one v_exp.
+__device__ __forceinline__ float ce_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
+    float poly = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erf_abs = 1.f - poly * t * e;
+    const float erf_x = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.f + erf_x);
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
-__global__ __launch_bounds__(256) void ce_gemm(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W,
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2 : 1)) void ce_gemm(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W,
                                                const float* __restrict__ bias, int M, int N, int K,
                                                unsigned short* __restrict__ outb, float* __restrict__ res32,
                                                const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps) {
-    static_assert(WAVES_M * WAVES_N == 4, "four waves per workgroup");
+    constexpr int THREADS = 64 * WAVES_M * WAVES_N;
     constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, MB = TM / 32, NB = TN / 32;
-    constexpr int A_CHUNKS = BM * 8 / 256, W_CHUNKS = BN * 8 / 256;      // 16-B pieces per thread and K tile
+    constexpr int A_CHUNKS = BM * 8 / THREADS, W_CHUNKS = BN * 8 / THREADS;      // 16-B pieces per thread and K tile
+    static_assert(BM * 8 % THREADS == 0 && BN * 8 % THREADS == 0, "tile rows must split evenly over the threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
     unsigned short* As = reinterpret_cast<unsigned short*>(ce_smem);           // [BM][CE_LDK]
     unsigned short* Ws = As + BM * CE_LDK;                                      // [BN][CE_LDK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int r32 = lane & 31, hh = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * BM;
-    const int col0 = blockIdx.y * BN;
+    // 1-D grid, XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so the
+    // column tiles of one row tile are given consecutive ids ON THE SAME XCD: they run together and share the A
+    // tile in that L2 (A is then read from HBM once instead of once per column tile; W is L2-resident everywhere).
+    const int NT = N / BN;
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int64_t mtile = (int64_t)(loc / NT) * 8 + xcd;
+    const int64_t row0 = mtile * BM;
+    const int col0 = (loc % NT) * BN;
+    if (row0 >= M) return;
 
     f32x16 acc[MB][NB];
 #pragma unroll
@@ -120,26 +141,26 @@ __global__ __launch_bounds__(256) void ce_gemm(const unsigned short* __restrict_
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
-            const int c = tid + 256 * i, r = c >> 3, p = c & 7;
+            const int c = tid + THREADS * i, r = c >> 3, p = c & 7;
             int64_t row = row0 + r;
             row = row < M ? row : M - 1;                                   // rows past M are never stored
             pa[i] = *reinterpret_cast<const u32x4*>(A + row * K + kt * 64 + p * 8);
         }
 #pragma unroll
         for (int i = 0; i < W_CHUNKS; ++i) {
-            const int c = tid + 256 * i, r = c >> 3, p = c & 7;
+            const int c = tid + THREADS * i, r = c >> 3, p = c & 7;
             pw[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)(col0 + r) * K + kt * 64 + p * 8);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
-            const int c = tid + 256 * i, r = c >> 3, p = c & 7;
+            const int c = tid + THREADS * i, r = c >> 3, p = c & 7;
             *reinterpret_cast<u32x4*>(As + r * CE_LDK + p * 8) = pa[i];
         }
 #pragma unroll
         for (int i = 0; i < W_CHUNKS; ++i) {
-            const int c = tid + 256 * i, r = c >> 3, p = c & 7;
+            const int c = tid + THREADS * i, r = c >> 3, p = c & 7;
             *reinterpret_cast<u32x4*>(Ws + r * CE_LDK + p * 8) = pw[i];
         }
     };
@@ -188,9 +209,9 @@ __global__ __launch_bounds__(256) void ce_gemm(const unsigned short* __restrict_
         // whole rows live in this workgroup (BN == N, WAVES_M == 1): x = acc + bias + residual, two-pass LayerNorm.
         // Row sums: in-lane over the wave's NB column blocks, a reduce-scatter butterfly over the 32 lanes of a
         // half (31 shuffles for the lane's MB*16 rows), the four waves' partials through LDS.
-        static_assert(WAVES_M == 1 && MB * 16 == 32, "LayerNorm epilogue: 64-row tile, one wave row");
-        float* red = reinterpret_cast<float*>(ce_smem);                     // [4][BM] partials, then [BM] result
-        float* stat = red + 4 * BM;                                          // [BM] mean, then rstd
+        static_assert(MB * 16 == 32, "LayerNorm epilogue: 64 rows per wave");
+        float* red = reinterpret_cast<float*>(ce_smem);                     // [WAVES_N][BM] partial row sums
+        float* stat = red + WAVES_N * BM;                                    // [2][BM] mean, rstd
         float bv[NB], gv[NB], be[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -201,13 +222,16 @@ __global__ __launch_bounds__(256) void ce_gemm(const unsigned short* __restrict_
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int64_t row = row0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 const int64_t rr = row < M ? row : M - 1;
 #pragma unroll
                 for (int j = 0; j < NB; ++j)
                     acc[i][j][e] = (acc[i][j][e] + bv[j]) + res32[rr * N + wn * TN + j * 32 + r32];
             }
-        float mean_l[MB * 16], rstd_l[MB * 16];
+        // pass 0: row means; pass 1: centred sums of squares.  The statistics stay in LDS (stat: mean, then rstd)
+        // and are re-read where needed, so the epilogue holds no per-row register arrays beside the accumulators.
+        float* mean_s = stat;                                                // [BM]
+        float* rstd_s = stat + BM;                                           // [BM]
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             float v[32];
@@ -215,10 +239,11 @@ __global__ __launch_bounds__(256) void ce_gemm(const unsigned short* __restrict_
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
+                    const float mu = pass == 0 ? 0.f : mean_s[wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh];
                     float s = 0.f;
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
-                        const float d = pass == 0 ? acc[i][j][e] : acc[i][j][e] - mean_l[i * 16 + e];
+                        const float d = acc[i][j][e] - mu;
                         s += pass == 0 ? d : d * d;
                     }
                     v[i * 16 + e] = s;
@@ -237,33 +262,30 @@ __global__ __launch_bounds__(256) void ce_gemm(const unsigned short* __restrict_
             // lane (r32, hh) now holds the wave's sum of slot s = r32: block i = s >> 4, e = s & 15
             {
                 const int s_ = r32, i = s_ >> 4, e = s_ & 15;
-                red[wave * BM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh] = v[0];
+                red[wn * BM + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh] = v[0];
             }
             __syncthreads();
             if (tid < BM) {
-                const float tot = (red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid]);
-                stat[tid] = pass == 0 ? tot * (1.f / BN) : rsqrtf(tot * (1.f / BN) + ln_eps);
+                float tot = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < WAVES_N; ++w_) tot += red[w_ * BM + tid];
+                if (pass == 0) mean_s[tid] = tot * (1.f / BN);
+                else rstd_s[tid] = rsqrtf(tot * (1.f / BN) + ln_eps);
             }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float sv = stat[i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh];
-                    if (pass == 0) mean_l[i * 16 + e] = sv; else rstd_l[i * 16 + e] = sv;
-                }
             __syncthreads();
         }
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t row = row0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int rt = wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int64_t row = row0 + rt;
                 if (row < M) {
+                    const float mu = mean_s[rt], rs = rstd_s[rt];
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
                         const int col = wn * TN + j * 32 + r32;
-                        const float y = (acc[i][j][e] - mean_l[i * 16 + e]) * rstd_l[i * 16 + e] * gv[j] + be[j];
+                        const float y = (acc[i][j][e] - mu) * rs * gv[j] + be[j];
                         res32[row * N + col] = y;
                         outb[row * N + col] = ce_bf16_bits(y);
                     }
@@ -314,30 +336,33 @@ __global__ __launch_bounds__(256) void ce_attention(const unsigned short* __rest
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qkv + (int64_t)(t0 + qrow) * (3 * CE_H) + head * CE_HD + g * 8);
         f32x4_t st[NT];
         float mx = -INFINITY;
+        // softmax in base 2 with the 1/sqrt(d) scale folded in: p = exp2(c1 * s - c1 * max); the raw scores are
+        // kept until the maximum is known (c1 > 0: the maximum of the raw scores is the maximum of the scaled ones)
+        const float c1 = scale * 1.4426950408889634f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt) {
             if (kt < n_tiles) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + c16) * CE_KS_LD + g * 8);
                 f32x4_t z = {0.f, 0.f, 0.f, 0.f};
                 z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);   // z[r] = S^T[key 16kt + 4g + r][q = c16]
+                if (kt * 16 + 16 > S) {                                            // only the last tiles hold padding keys
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float s = (kt * 16 + 4 * g + r) < S ? z[r] * scale : -INFINITY;
-                    z[r] = s;
-                    mx = fmaxf(mx, s);
+                    for (int r = 0; r < 4; ++r) z[r] = (kt * 16 + 4 * g + r) < S ? z[r] : -INFINITY;
                 }
+                mx = fmaxf(fmaxf(mx, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
                 st[kt] = z;
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmx = -mx * c1;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NT; ++kt)
             if (kt < n_tiles) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(st[kt][r] - mx);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c1, nmx));
                     st[kt][r] = p;
                     sum += p;
                 }
@@ -561,6 +586,12 @@ static int ce_reserve(rr_ce* ce, int64_t tokens) {
     return RR_OK;
 }
 
+// workgroups of the XCD-aware 1-D GEMM grid: row tiles rounded up to a multiple of 8 (one per XCD), times column tiles
+static unsigned ce_grid(int M, int BM, int n_col_tiles) {
+    const int mt = (M + BM - 1) / BM;
+    return (unsigned)(((mt + 7) / 8) * 8 * n_col_tiles);
+}
+
 template <int NT>
 static void ce_launch_attention(rr_ce* ce, const int32_t* d_cu, int P, hipStream_t st) {
     const size_t lds = (size_t)(NT * 16) * CE_KS_LD * 2 + (size_t)32 * (NT * 16 + 8) * 2;
@@ -587,10 +618,10 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     static bool attr_set = false;
     if (!attr_set) {
         // dynamic LDS above 64 KB must be opted into per kernel
-        const int ldsA = (128 + 128) * CE_LDK * 2, ldsB = (64 + 384) * CE_LDK * 2;
+        const int ldsA = (128 + 128) * CE_LDK * 2, ldsB = (128 + 384) * CE_LDK * 2;
         hipFuncSetAttribute((const void*)ce_gemm<128, 128, 2, 2, CE_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsA);
         hipFuncSetAttribute((const void*)ce_gemm<128, 128, 2, 2, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsA);
-        hipFuncSetAttribute((const void*)ce_gemm<64, 384, 1, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
+        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
         hipFuncSetAttribute((const void*)ce_attention<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             512 * CE_KS_LD * 2 + 32 * (512 + 8) * 2);
         hipFuncSetAttribute((const void*)ce_attention<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -601,21 +632,20 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     hipLaunchKernelGGL(ce_embed_ln, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, d_token_ids, d_type_ids, d_pos_ids, T,
                        ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type, ce->eln_g, ce->eln_b,
                        ce->cfg.ln_eps, ce->h32, ce->hb);
-    const size_t ldsA = (size_t)(128 + 128) * CE_LDK * 2, ldsB = (size_t)(64 + 384) * CE_LDK * 2;
-    const unsigned gmA = (unsigned)((T + 127) / 128), gmB = (unsigned)((T + 63) / 64);
+    const size_t ldsA = (size_t)(128 + 128) * CE_LDK * 2, ldsB = (size_t)(128 + 384) * CE_LDK * 2;
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
-        hipLaunchKernelGGL((ce_gemm<128, 128, 2, 2, CE_EPI_BIAS>), dim3(gmA, 3 * CE_H / 128), dim3(256), ldsA, st, ce->hb, L.wqkv,
+        hipLaunchKernelGGL((ce_gemm<128, 128, 2, 2, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 128)), dim3(256), ldsA, st, ce->hb, L.wqkv,
                            L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
         if (max_len <= 64) ce_launch_attention<4>(ce, d_cu_seqlens, n_seqs, st);
         else if (max_len <= 128) ce_launch_attention<8>(ce, d_cu_seqlens, n_seqs, st);
         else if (max_len <= 256) ce_launch_attention<16>(ce, d_cu_seqlens, n_seqs, st);
         else ce_launch_attention<32>(ce, d_cu_seqlens, n_seqs, st);
-        hipLaunchKernelGGL((ce_gemm<64, 384, 1, 4, CE_EPI_RES_LN>), dim3(gmB, 1), dim3(256), ldsB, st, ce->ctx, L.wo, L.bo, T, CE_H,
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(T, 128, 1)), dim3(512), ldsB, st, ce->ctx, L.wo, L.bo, T, CE_H,
                            CE_H, ce->hb, ce->h32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
-        hipLaunchKernelGGL((ce_gemm<128, 128, 2, 2, CE_EPI_GELU>), dim3(gmA, CE_FFN / 128), dim3(256), ldsA, st, ce->hb, L.w1, L.b1, T,
+        hipLaunchKernelGGL((ce_gemm<128, 128, 2, 2, CE_EPI_GELU>), dim3(ce_grid(T, 128, CE_FFN / 128)), dim3(256), ldsA, st, ce->hb, L.w1, L.b1, T,
                            CE_FFN, CE_H, ce->inter, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
-        hipLaunchKernelGGL((ce_gemm<64, 384, 1, 4, CE_EPI_RES_LN>), dim3(gmB, 1), dim3(256), ldsB, st, ce->inter, L.w2, L.b2, T, CE_H,
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(T, 128, 1)), dim3(512), ldsB, st, ce->inter, L.w2, L.b2, T, CE_H,
                            CE_FFN, ce->hb, ce->h32, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
     }
     if (mode == RR_CE_OUT_HIDDEN)

@@ -90,6 +90,35 @@ def exchange(buf, world: int, group=None):
     return out
 
 
+def split_pairs(n_pairs: int, world: int, rank: int) -> Tuple[int, int]:
+    """Even split of the flattened (query, candidate) pair list of the rerank step across ranks
+    ("pairs B x 200 are split evenly across ranks after the merge"): the same rule as shard_bounds."""
+    return shard_bounds(n_pairs, world, rank)
+
+
+def exchange_scores(local, n_pairs: int, world: int, group=None):
+    """The second, tiny all-gather of the rerank flow (only when rerank_k > 0): every rank contributes the
+    reranker scores of its share of the pairs (float32 tensor of split_pairs' length); returns the full
+    (n_pairs,) tensor, identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local
+    share = (n_pairs + world - 1) // world                     # shares differ by at most one pair: pad to the longest
+    buf = torch.zeros(share, dtype=torch.float32, device=local.device)
+    buf[:local.numel()] = local
+    out = torch.empty(world * share, dtype=torch.float32, device=local.device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, buf, group=group)
+    else:
+        dist.all_gather([out[r * share:(r + 1) * share] for r in range(world)], buf, group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = split_pairs(n_pairs, world, r)
+        parts.append(out[r * share:r * share + (hi - lo)])
+    return torch.cat(parts)
+
+
 class ShardedSearcher:
     """K1 + K2 per shard, one all-gather, K3 on the merged pool."""
 
@@ -121,37 +150,82 @@ class ShardedSearcher:
 
     def search_batch_dev(self, q_dev, term_id_lists: Optional[Sequence[Sequence[int]]], k: int,
                          weights: Optional[FusionWeights] = None, pool_floor: int = 150,
-                         bm25_mode: str = "forward"):
-        """Device-resident queries in, device tensors out: (pool_rows, columns, order)."""
+                         bm25_mode: str = "forward", rerank_k: int = 0, gate_fn=None, rerank_fn=None):
+        """Device-resident queries in, device tensors out: (pool_rows, columns, order).
+
+        ``gate_fn(rows (B, pool) global rows, numpy) -> (B, pool) float32`` and
+        ``rerank_fn(query_idx (n,), rows (n,)) -> (n,) float32`` (scores of the (query, product) pairs given) are
+        host callables over the MERGED pool (app/app_product_search.py:271-303): the shards' candidates are
+        merged first (K3 with k = pool gives the pool order), gate strings are matched on the host, the
+        B x rr_k reranker pairs are split evenly across the ranks, their scores gathered with a second tiny
+        all-gather, and K3 runs again on the same gathered payload with the pool-aligned columns."""
         import torch
         w = weights or FusionWeights()
         B = q_dev.shape[0]
-        pool = min(max(k, pool_floor), self.n_total)
+        pool = min(max(k, rerank_k, pool_floor), self.n_total)
         pool_local = min(pool, self.s.index.n_rows)
+        rr_k = min(rerank_k, pool)
         if self.world > 1:
             # every rank must contribute the same count for the strided addressing
             assert pool_local == pool, "each shard needs at least `pool` rows"
         tl = term_id_lists if term_id_lists is not None else [[] for _ in range(B)]
+        s = self.s
+        two_pass = gate_fn is not None or (rerank_fn is not None and rr_k > 0)
         if self.world == 1 and not self.force_payload:
             # nothing to exchange: K1 -> K2 -> K3 straight through, metadata read from the index
-            s = self.s
             rows, dense = s.dense_pool(q_dev, pool)
             bm = s.bm25_at(tl, rows, bm25_mode)
-            return s.fuse(HybridSearcher.make_params(w, min(k, pool), pool, pool, 0), B, rows, dense, bm)
+            gate = rerank = None
+            if two_pass:
+                gate, rerank = self._pool_columns(rows, B, pool, rr_k, gate_fn, rerank_fn)
+            return s.fuse(HybridSearcher.make_params(w, min(k, pool), pool, pool, rr_k), B, rows, dense, bm,
+                          None, rerank, None, gate)
         lay, buf = self.local_payload(q_dev, tl, pool_local, bm25_mode)
         gathered = exchange(buf, self.world, self.group)
         base = gathered.data_ptr()
         ptr = lambda off: C.c_void_p(base + off)
-        params = HybridSearcher.make_params(w, min(k, pool), pool, self.world * pool_local, 0,
-                                            cand_per_rank=pool_local, stride_bytes=lay.nbytes)
-        s = self.s
-        out_rows = torch.empty((B, pool), dtype=torch.int64, device=s.device)
-        cols = torch.empty((B, 8, pool), dtype=torch.float64, device=s.device)
-        order = torch.empty((B, params.k), dtype=torch.int32, device=s.device)
-        _lib.check(s.lib.rr_fuse_topk_dev(
-            s.index.handle, C.byref(params), B, ptr(lay.off_rows), ptr(lay.off_dense), ptr(lay.off_bm25),
-            ptr(lay.off_n), ptr(lay.off_avg), ptr(lay.off_l1p), None, None, None,
-            C.c_void_p(out_rows.data_ptr()), C.c_void_p(cols.data_ptr()), C.c_void_p(order.data_ptr()),
-            s._stream()), "rr_fuse_topk_dev")
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+        def fuse(k_out, rerank, gate, rr):
+            params = HybridSearcher.make_params(w, k_out, pool, self.world * pool_local, rr,
+                                                cand_per_rank=pool_local, stride_bytes=lay.nbytes)
+            out_rows = torch.empty((B, pool), dtype=torch.int64, device=s.device)
+            cols = torch.empty((B, 8, pool), dtype=torch.float64, device=s.device)
+            order = torch.empty((B, params.k), dtype=torch.int32, device=s.device)
+            _lib.check(s.lib.rr_fuse_topk_dev(
+                s.index.handle, C.byref(params), B, ptr(lay.off_rows), ptr(lay.off_dense), ptr(lay.off_bm25),
+                ptr(lay.off_n), ptr(lay.off_avg), ptr(lay.off_l1p), p(rerank), None, p(gate),
+                p(out_rows), p(cols), p(order), s._stream()), "rr_fuse_topk_dev")
+            return out_rows, cols, order
+
+        if not two_pass:
+            res = fuse(min(k, pool), None, None, 0)
+        else:
+            merged_rows, _, _ = fuse(pool, None, None, 0)           # pass A: the merge alone fixes the pool order
+            gate, rerank = self._pool_columns(merged_rows, B, pool, rr_k, gate_fn, rerank_fn)
+            res = fuse(min(k, pool), rerank, gate, rr_k)             # pass B: same payload + pool-aligned columns
         self._keep = (gathered, buf)   # alive until the stream has consumed them
-        return out_rows, cols, order
+        return res
+
+    def _pool_columns(self, rows_dev, B: int, pool: int, rr_k: int, gate_fn, rerank_fn):
+        """Gate factors (every rank, all pairs: string work on replicated texts) and reranker scores (this rank's
+        share of the B x rr_k pairs + the score all-gather) for the merged pool; device tensors or None."""
+        import torch
+        s = self.s
+        rows_h = rows_dev.cpu().numpy()
+        gate = rerank = None
+        if gate_fn is not None:
+            g = np.ascontiguousarray(gate_fn(rows_h), dtype=np.float32)
+            gate = torch.from_numpy(g).to(s.device)
+        if rerank_fn is not None and rr_k > 0:
+            n_pairs = B * rr_k
+            lo, hi = split_pairs(n_pairs, self.world, self.rank)
+            idx = np.arange(lo, hi)
+            qi, ci = idx // rr_k, idx % rr_k
+            mine = np.asarray(rerank_fn(qi, rows_h[qi, ci]), dtype=np.float32).reshape(-1)
+            if mine.shape[0] != hi - lo:
+                raise ValueError("rerank_fn must return one score per pair")
+            full = exchange_scores(torch.from_numpy(mine).to(s.device), n_pairs, self.world, self.group)
+            rerank = torch.zeros((B, pool), dtype=torch.float32, device=s.device)
+            rerank[:, :rr_k] = full.view(B, rr_k)
+        return gate, rerank

@@ -72,3 +72,90 @@ def test_sharded_equals_unsharded_bitwise(world, batch):
     assert np.array_equal(order.cpu().numpy(), want_order)
     r0 = want_rows[0].tolist()
     assert r0.index(1000) + 1 == r0.index(39_000)      # tie: ascending global row
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_config4_shape_bf16_batch_256_sharded_equals_unsharded(dtype):
+    """BASELINE config 4's shape on one GPU: batch 256 (two 128-query filter-scan launches per shard), bf16 or
+    fp32 storage, 8 shards: merged answer == unsharded answer, bit for bit."""
+    n, vocab, world, batch, k, pool = 640_000, 5000, 8, 256, 100, 150
+    V = synth.unit_rows(n, 384, 71)
+    n_rev, stars = synth.metadata(n, 72, nan_fraction=0.0)
+    ip, terms, tf, dl = synth.bm25_forward_csr(n, vocab, 20, 73)
+    corpus = BM25Corpus(ip, terms, tf, dl, vocab)
+    Q = synth.unit_rows(batch, 384, 74)
+    tl = synth.query_terms(batch, vocab, 75, np.bincount(terms, minlength=vocab))
+    w = FusionWeights(w_dense=0.5, w_bm25=0.5, w_rerank=0.0, w_prior=0.0, w_best=0.0, gate_penalty=1.0)
+
+    def build_t(lo, hi):
+        ix = ProductIndex.from_rows(V[lo:hi], row_offset=lo, dtype=dtype)
+        ix.set_meta(n_rev[lo:hi].astype(np.float64), stars[lo:hi])
+        return HybridSearcher(ix, corpus.slice(lo, hi).to_device(row_offset=lo))
+
+    q_dev = torch.from_numpy(Q).cuda()
+    whole = ShardedSearcher(build_t(0, n), n, 0, 1)
+    want = [t.cpu().numpy() for t in whole.search_batch_dev(q_dev, tl, k, w)]
+    lay = PayloadLayout(batch, pool)
+    gathered = torch.empty((world, lay.nbytes), dtype=torch.uint8, device="cuda")
+    first = None
+    for r in range(world):
+        lo, hi = shard_bounds(n, world, r)
+        sh = ShardedSearcher(build_t(lo, hi), n, r, world)
+        _, buf = sh.local_payload(q_dev, tl, pool)
+        gathered[r].copy_(buf)
+        torch.cuda.synchronize()
+        first = first or sh
+    s0 = first.s
+    params = HybridSearcher.make_params(w, k, pool, world * pool, 0, cand_per_rank=pool, stride_bytes=lay.nbytes)
+    out_rows = torch.empty((batch, pool), dtype=torch.int64, device="cuda")
+    cols = torch.empty((batch, 8, pool), dtype=torch.float64, device="cuda")
+    order = torch.empty((batch, k), dtype=torch.int32, device="cuda")
+    base = gathered.data_ptr()
+    p = lambda off: C.c_void_p(base + off)
+    _lib.check(s0.lib.rr_fuse_topk_dev(
+        s0.index.handle, C.byref(params), batch, p(lay.off_rows), p(lay.off_dense), p(lay.off_bm25),
+        p(lay.off_n), p(lay.off_avg), p(lay.off_l1p), None, None, None, C.c_void_p(out_rows.data_ptr()),
+        C.c_void_p(cols.data_ptr()), C.c_void_p(order.data_ptr()), s0._stream()), "rr_fuse_topk_dev")
+    torch.cuda.synchronize()
+    assert np.array_equal(out_rows.cpu().numpy(), want[0])
+    assert np.array_equal(cols.cpu().numpy(), want[1], equal_nan=True)
+    assert np.array_equal(order.cpu().numpy(), want[2])
+
+
+def test_gate_and_rerank_columns_travel_through_the_payload_path():
+    """configs with gate_penalty < 1 or rerank_k > 0 on the sharded path.  The payload + merge
+    path (forced on one rank) with host gate / rerank callables over the MERGED pool must equal the straight
+    K1 -> K2 -> K3 path with the same callables, bit for bit; the rerank callable sees exactly its rank's share."""
+    n, vocab, batch, k, rr_k = 60_000, 3000, 6, 20, 200
+    V = synth.unit_rows(n, 384, 81)
+    n_rev, stars = synth.metadata(n, 82)
+    ip, terms, tf, dl = synth.bm25_forward_csr(n, vocab, 25, 83)
+    corpus = BM25Corpus(ip, terms, tf, dl, vocab)
+    Q = synth.unit_rows(batch, 384, 84)
+    tl = synth.query_terms(batch, vocab, 85, np.bincount(terms, minlength=vocab))
+    w = FusionWeights(w_dense=0.4, w_bm25=0.2, w_rerank=0.3, w_prior=0.1, w_best=0.0, gate_penalty=0.5)
+    seen = []
+
+    def gate_fn(rows):
+        return np.where(rows % 3 == 0, 0.5, 1.0).astype(np.float32)
+
+    def rerank_fn(qi, rows):
+        seen.append((qi.copy(), rows.copy()))
+        return (np.sin(rows * 0.001) + qi * 0.1).astype(np.float32)
+
+    q_dev = torch.from_numpy(Q).cuda()
+    sh = ShardedSearcher(build(V, n_rev.astype(np.float64), stars, corpus, 0, n), n, 0, 1)
+    a = [t.cpu().numpy() for t in sh.search_batch_dev(q_dev, tl, k, w, rerank_k=rr_k, gate_fn=gate_fn, rerank_fn=rerank_fn)]
+    sh.force_payload = True
+    b = [t.cpu().numpy() for t in sh.search_batch_dev(q_dev, tl, k, w, rerank_k=rr_k, gate_fn=gate_fn, rerank_fn=rerank_fn)]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    pool = a[0].shape[1]
+    assert pool == 200 and a[1].shape == (batch, 8, pool)
+    assert all(len(qi) == batch * rr_k for qi, _ in seen)                 # world 1: the whole pair list
+    assert np.array_equal(seen[0][1].reshape(batch, rr_k), a[0][:, :rr_k])  # pairs are the pool's first rr_k rows, in order
+    gate_col, rr_col = a[1][:, 5], a[1][:, 3]
+    assert np.array_equal(gate_col, gate_fn(a[0]).astype(np.float64))
+    assert np.all(rr_col.max(axis=1) > 0.999) and np.all(rr_col.min(axis=1) == 0)   # min-max of the reranker scores
+    no_gate = [t.cpu().numpy() for t in sh.search_batch_dev(q_dev, tl, k, w, rerank_k=rr_k, rerank_fn=rerank_fn)]
+    assert not np.array_equal(no_gate[1][:, 7], a[1][:, 7])

@@ -107,3 +107,41 @@ def test_two_rank_exchange_and_merge_addressing():
             assert float(at(lay.off_bm25, np.float32, q, i)) == row * 0.5
             assert float(at(lay.off_n, np.float64, q, i)) == float(n_rev[row])
             assert float(at(lay.off_avg, np.float64, q, i)) == float(stars[row])
+
+
+def _rerank_worker(rank, world, port, n_pairs, ret):
+    from review_recommender_amd.sharded import exchange_scores, split_pairs
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # first collective: the payload all-gather (as above); second: the scores of this rank's share of the pairs
+        buf = torch.full((64,), rank, dtype=torch.uint8)
+        g = exchange(buf, world)
+        lo, hi = split_pairs(n_pairs, world, rank)
+        mine = torch.arange(lo, hi, dtype=torch.float32) * 0.25 - 3.0      # score(pair i) = i / 4 - 3
+        full = exchange_scores(mine, n_pairs, world)
+        ret[rank] = (g.numpy().copy(), full.numpy().copy(), (lo, hi))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [64 * 200, 7, 1])
+def test_rerank_flow_two_collectives_config5(n_pairs):
+    """BASELINE config 5's second exchange: after the merge the B x rr_k reranker pairs are split
+    evenly across the ranks, every rank scores its share, one tiny all-gather gives every rank all scores."""
+    from review_recommender_amd.sharded import split_pairs
+    world = 2
+    port = free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rerank_worker, args=(world, port, n_pairs, ret), nprocs=world, join=True)
+    want = np.arange(n_pairs, dtype=np.float32) * 0.25 - 3.0
+    spans = [ret[r][2] for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n_pairs and spans[0][1] == spans[1][0]
+    assert abs((spans[0][1] - spans[0][0]) - (spans[1][1] - spans[1][0])) <= 1
+    for r in range(world):
+        assert np.array_equal(ret[r][1], want)                       # every pair exactly once, in order, on every rank
+        assert np.array_equal(ret[r][0][0], np.zeros(64, np.uint8)) and np.array_equal(ret[r][0][1], np.ones(64, np.uint8))
+    for w_ in (1, 3, 8):
+        cover = [split_pairs(n_pairs, w_, r) for r in range(w_)]
+        assert cover[0][0] == 0 and cover[-1][1] == n_pairs and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
