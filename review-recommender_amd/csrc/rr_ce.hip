@@ -14,13 +14,14 @@
 //
 // Kernels (per layer: 4 GEMMs + 1 attention; MFMA-bound, ~4.3 MFLOP per token and layer at 512 tokens):
 //   ce_embed_ln      word + position + type embedding, LayerNorm               (HBM-bound, one wave per token)
-//   ce_gemm<128x128> out = A W^T + b [, GELU] -> bf16      (QKV 384->1152, FFN1 384->1536)
-//   ce_gemm<128x384> out = LayerNorm(A W^T + b + residual) -> fp32 + bf16      (attention output, FFN2 1536->384):
-//                    a workgroup owns whole rows, so the normalisation is fused into the epilogue
-//   ce_attention     one workgroup per (sequence, head): K and V^T of the head in LDS, S^T = K Q^T on
-//                    v_mfma_f32_16x16x32_bf16 (K = head dim = 32: one MFMA per 16x16 score tile), softmax in
-//                    registers, and the probability tile is fed straight back as the A operand of P V (the
-//                    accumulator-as-operand idiom: no lane movement, no LDS round trip)
+//   ce_gemm<128x384> eight waves (2 x 4, 64 x 96 per wave), one workgroup per CU at two waves per SIMD; epilogues:
+//                    out = A W^T + b [, GELU] -> bf16                          (QKV 384->1152, FFN1 384->1536)
+//                    out = LayerNorm(A W^T + b + residual) -> fp32 + bf16      (attention output, FFN2 1536->384):
+//                    a workgroup owns whole rows (BN = hidden), so the normalisation is fused into the epilogue
+//   ce_attention     one workgroup (eight waves) per (sequence, head): K and V^T of the head in LDS, S^T = K Q^T on
+//                    v_mfma_f32_16x16x32_bf16 (K = head dim = 32: one MFMA per 16x16 score tile), base-2 online
+//                    softmax over 128-key chunks in registers, and the probability tile is fed straight back as
+//                    the A operand of P V (the accumulator-as-operand idiom: no lane movement, no LDS round trip)
 //   ce_head          pooler (tanh) + classifier on the [CLS] rows, fp32
 // GEMM tiles: 32x32x16 bf16 MFMA, K-step 64 through LDS rows padded to 144 B (conflict-free ds_read_b128),
 // next K tile prefetched global -> registers under the MFMAs of the current one.
@@ -298,14 +299,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define CE_KS_LD 40         // K rows in LDS: 32 bf16 + 8 pad = 80 B (conflict-free ds_read_b128 over 16 rows)
 
-template <int NT>           // NT = upper bound of 16-key tiles for this launch (multiple of 2)
-__global__ __launch_bounds__(256) void ce_attention(const unsigned short* __restrict__ qkv, const int32_t* __restrict__ cu,
-                                                    unsigned short* __restrict__ ctx, float scale) {
-    constexpr int SMAX = NT * 16;
-    constexpr int VT_LD = SMAX + 8;
+#define CE_ATT_THREADS 512     // eight waves share one (sequence, head): K and V^T are staged once for all of them
+#define CE_ATT_CH 8            // 16-key tiles per online-softmax chunk (128 keys)
+
+__global__ __launch_bounds__(CE_ATT_THREADS, 2) void ce_attention(const unsigned short* __restrict__ qkv,
+                                                                  const int32_t* __restrict__ cu,
+                                                                  unsigned short* __restrict__ ctx, float scale, int smax_pad) {
+    const int VT_LD = smax_pad + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
-    unsigned short* Ks = reinterpret_cast<unsigned short*>(ce_smem);          // [SMAX][CE_KS_LD]
-    unsigned short* Vt = Ks + SMAX * CE_KS_LD;                                  // [32][VT_LD]   V transposed
+    unsigned short* Ks = reinterpret_cast<unsigned short*>(ce_smem);          // [smax_pad][CE_KS_LD]
+    unsigned short* Vt = Ks + smax_pad * CE_KS_LD;                              // [32][VT_LD]   V transposed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int seq = blockIdx.x, head = blockIdx.y;
     const int t0 = cu[seq], S = cu[seq + 1] - t0;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void ce_attention(const unsigned short* __rest
     const int c16 = lane & 15, g = lane >> 4;
 
     // stage K (row major) and V^T of this head; rows past S are zero
-    for (int c = tid; c < Spad * 4; c += 256) {
+    for (int c = tid; c < Spad * 4; c += CE_ATT_THREADS) {
         const int r = c >> 2, p = c & 3;
         u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
         if (r < S) {
@@ -328,77 +331,84 @@ __global__ __launch_bounds__(256) void ce_attention(const unsigned short* __rest
     }
     __syncthreads();
 
-    const int n_tiles = Spad >> 4;
-    for (int qb = wave; qb * 16 < S; qb += 4) {
+    const int n_tiles = Spad >> 4;                       // even
+    // softmax in base 2 with the 1/sqrt(d) scale folded in: p = exp2(c1 * s - c1 * max), streamed over chunks of
+    // 128 keys with a running maximum (raw scores; c1 > 0) and running sums, the accumulators rescaled per chunk
+    const float c1 = scale * 1.4426950408889634f;
+    for (int qb = wave; qb * 16 < S; qb += CE_ATT_THREADS / 64) {
         // B operand of S^T = K Q^T: lane (q = c16, g) holds Q[q][8g .. 8g+7]
         int qrow = qb * 16 + c16;
         qrow = qrow < S ? qrow : S - 1;
         const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qkv + (int64_t)(t0 + qrow) * (3 * CE_H) + head * CE_HD + g * 8);
-        f32x4_t st[NT];
-        float mx = -INFINITY;
-        // softmax in base 2 with the 1/sqrt(d) scale folded in: p = exp2(c1 * s - c1 * max); the raw scores are
-        // kept until the maximum is known (c1 > 0: the maximum of the raw scores is the maximum of the scaled ones)
-        const float c1 = scale * 1.4426950408889634f;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-            if (kt < n_tiles) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + c16) * CE_KS_LD + g * 8);
-                f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-                z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);   // z[r] = S^T[key 16kt + 4g + r][q = c16]
-                if (kt * 16 + 16 > S) {                                            // only the last tiles hold padding keys
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) z[r] = (kt * 16 + 4 * g + r) < S ? z[r] : -INFINITY;
-                }
-                mx = fmaxf(fmaxf(mx, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
-                st[kt] = z;
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float nmx = -mx * c1;
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NT; ++kt)
-            if (kt < n_tiles) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c1, nmx));
-                    st[kt][r] = p;
-                    sum += p;
-                }
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        // out[q][d] = sum_k P[q][k] V[k][d]: the probability tiles are the A operand as they sit (lane = q column,
-        // registers = keys); two 16-key tiles form one K = 32 step whose key order is
-        //   element j of lane group g:  j < 4 -> key 32u + 4g + j,   j >= 4 -> key 32u + 16 + 4g + (j - 4)
-        // and V^T is read in that same order.
+        float m_run = -INFINITY, l_run = 0.f;             // of query column c16 (l: this lane's keys only until the end)
         f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < n_tiles; kc += CE_ATT_CH) {
+            f32x4_t st[CE_ATT_CH];
+            float cm = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < NT / 2; ++u)
-            if (2 * u < n_tiles) {
-                bf16x8 pf;
+            for (int i = 0; i < CE_ATT_CH; ++i) {
+                const int kt = kc + i;
+                if (kt < n_tiles) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 16 + c16) * CE_KS_LD + g * 8);
+                    f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+                    z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);   // z[r] = S^T[key 16kt + 4g + r][q = c16]
+                    if (kt * 16 + 16 > S) {                                            // only the last tiles hold padding keys
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    pf[r] = (__bf16)st[2 * u][r];
-                    pf[4 + r] = (__bf16)st[2 * u + 1][r];
+                        for (int r = 0; r < 4; ++r) z[r] = (kt * 16 + 4 * g + r) < S ? z[r] : -INFINITY;
+                    }
+                    cm = fmaxf(fmaxf(cm, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
+                    st[i] = z;
                 }
-                bf16x8 v0, v1;
-                {
-                    const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(Vt + c16 * VT_LD + 32 * u + 4 * g);
-                    const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(Vt + c16 * VT_LD + 32 * u + 16 + 4 * g);
-                    const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(Vt + (16 + c16) * VT_LD + 32 * u + 4 * g);
-                    const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(Vt + (16 + c16) * VT_LD + 32 * u + 16 + 4 * g);
+            }
+            cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+            cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+            const float m_new = fmaxf(m_run, cm);              // finite: key 0 of chunk 0 is never masked
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c1);   // exp2(-inf) = 0 on the first chunk
+            const float nmx = -m_new * c1;
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                      // accumulator row q = 4g + r: the factor of that query
+                const float a = __shfl(alpha, 4 * g + r, 64);
+                o0[r] *= a;
+                o1[r] *= a;
+            }
+            // out[q][d] += sum_k P[q][k] V[k][d]: the probability tiles are the A operand as they sit (lane = q column,
+            // registers = keys); two 16-key tiles form one K = 32 step whose key order is
+            //   element j of lane group g:  j < 4 -> key 32u + 4g + j,   j >= 4 -> key 32u + 16 + 4g + (j - 4)
+            // and V^T is read in that same order.
+#pragma unroll
+            for (int i = 0; i < CE_ATT_CH; i += 2) {
+                const int kt = kc + i;
+                if (kt < n_tiles) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i][r], c1, nmx));
+                        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i + 1][r], c1, nmx));
+                        l_run += p0 + p1;
+                        pf[r] = (__bf16)p0;
+                        pf[4 + r] = (__bf16)p1;
+                    }
+                    const unsigned short* vb = Vt + c16 * VT_LD + 16 * kt + 4 * g;
+                    const bf16x4 a0 = *reinterpret_cast<const bf16x4*>(vb);
+                    const bf16x4 a1 = *reinterpret_cast<const bf16x4*>(vb + 16);
+                    const bf16x4 b0 = *reinterpret_cast<const bf16x4*>(vb + 16 * VT_LD);
+                    const bf16x4 b1 = *reinterpret_cast<const bf16x4*>(vb + 16 * VT_LD + 16);
+                    bf16x8 v0, v1;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v0[r] = a0[r]; v0[4 + r] = a1[r]; v1[r] = b0[r]; v1[4 + r] = b1[r]; }
+                    o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, v0, o0, 0, 0, 0);    // o[r] = out[q = 4g + r][d = c16]
+                    o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, v1, o1, 0, 0, 0);    //                     [d = 16 + c16]
                 }
-                o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, v0, o0, 0, 0, 0);    // o[r] = out[q = 4g + r][d = c16]
-                o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, v1, o1, 0, 0, 0);    //                     [d = 16 + c16]
             }
+        }
+        l_run += __shfl_xor(l_run, 16, 64);
+        l_run += __shfl_xor(l_run, 32, 64);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = qb * 16 + 4 * g + r;
-            const float inv = 1.f / __shfl(sum, 4 * g + r, 64);          // lane 4g + r holds the sum of query column 4g + r
+            const float inv = 1.f / __shfl(l_run, 4 * g + r, 64);          // lane 4g + r holds the sum of query column 4g + r
             if (q < S) {
                 unsigned short* dst = ctx + (int64_t)(t0 + q) * CE_H + head * CE_HD;
                 dst[c16] = ce_bf16_bits(o0[r] * inv);
@@ -592,12 +602,7 @@ static unsigned ce_grid(int M, int BM, int n_col_tiles) {
     return (unsigned)(((mt + 7) / 8) * 8 * n_col_tiles);
 }
 
-template <int NT>
-static void ce_launch_attention(rr_ce* ce, const int32_t* d_cu, int P, hipStream_t st) {
-    const size_t lds = (size_t)(NT * 16) * CE_KS_LD * 2 + (size_t)32 * (NT * 16 + 8) * 2;
-    hipLaunchKernelGGL((ce_attention<NT>), dim3((unsigned)P, CE_HEADS), dim3(256), lds, st, ce->qkv, d_cu, ce->ctx,
-                       0.17677669529663687f /* 1 / sqrt(32) */);
-}
+static size_t ce_attention_lds(int smax_pad) { return (size_t)smax_pad * CE_KS_LD * 2 + (size_t)32 * (smax_pad + 8) * 2; }
 
 extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_type_ids,
                                  const int32_t* d_pos_ids, const int32_t* d_cu_seqlens, int32_t n_seqs,
@@ -618,32 +623,28 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     static bool attr_set = false;
     if (!attr_set) {
         // dynamic LDS above 64 KB must be opted into per kernel
-        const int ldsA = (128 + 128) * CE_LDK * 2, ldsB = (128 + 384) * CE_LDK * 2;
-        hipFuncSetAttribute((const void*)ce_gemm<128, 128, 2, 2, CE_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsA);
-        hipFuncSetAttribute((const void*)ce_gemm<128, 128, 2, 2, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsA);
+        const int ldsB = (128 + 384) * CE_LDK * 2;
+        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
+        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
         hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
-        hipFuncSetAttribute((const void*)ce_attention<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            512 * CE_KS_LD * 2 + 32 * (512 + 8) * 2);
-        hipFuncSetAttribute((const void*)ce_attention<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            256 * CE_KS_LD * 2 + 32 * (256 + 8) * 2);
+        hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512));
         attr_set = true;
     }
+    const int smax_pad = (max_len + 31) & ~31;
     hipEventRecord(ce->ev0, st);
     hipLaunchKernelGGL(ce_embed_ln, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, d_token_ids, d_type_ids, d_pos_ids, T,
                        ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type, ce->eln_g, ce->eln_b,
                        ce->cfg.ln_eps, ce->h32, ce->hb);
-    const size_t ldsA = (size_t)(128 + 128) * CE_LDK * 2, ldsB = (size_t)(128 + 384) * CE_LDK * 2;
+    const size_t ldsB = (size_t)(128 + 384) * CE_LDK * 2;
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
-        hipLaunchKernelGGL((ce_gemm<128, 128, 2, 2, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 128)), dim3(256), ldsA, st, ce->hb, L.wqkv,
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 384)), dim3(512), ldsB, st, ce->hb, L.wqkv,
                            L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
-        if (max_len <= 64) ce_launch_attention<4>(ce, d_cu_seqlens, n_seqs, st);
-        else if (max_len <= 128) ce_launch_attention<8>(ce, d_cu_seqlens, n_seqs, st);
-        else if (max_len <= 256) ce_launch_attention<16>(ce, d_cu_seqlens, n_seqs, st);
-        else ce_launch_attention<32>(ce, d_cu_seqlens, n_seqs, st);
+        hipLaunchKernelGGL(ce_attention, dim3((unsigned)n_seqs, CE_HEADS), dim3(CE_ATT_THREADS), ce_attention_lds(smax_pad), st,
+                           ce->qkv, d_cu_seqlens, ce->ctx, 0.17677669529663687f /* 1 / sqrt(32) */, smax_pad);
         hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(T, 128, 1)), dim3(512), ldsB, st, ce->ctx, L.wo, L.bo, T, CE_H,
                            CE_H, ce->hb, ce->h32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
-        hipLaunchKernelGGL((ce_gemm<128, 128, 2, 2, CE_EPI_GELU>), dim3(ce_grid(T, 128, CE_FFN / 128)), dim3(256), ldsA, st, ce->hb, L.w1, L.b1, T,
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(T, 128, CE_FFN / 384)), dim3(512), ldsB, st, ce->hb, L.w1, L.b1, T,
                            CE_FFN, CE_H, ce->inter, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
         hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(T, 128, 1)), dim3(512), ldsB, st, ce->inter, L.w2, L.b2, T, CE_H,
                            CE_FFN, ce->hb, ce->h32, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);

@@ -570,10 +570,10 @@ int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t
 }
 
 // Timing-only ablations of the 128-query fp32 filter scan (tools/flt_ablate.py).  Garbage in the scratch afterwards.
-template <int DBG>
+template <int DBG, bool PLANE = false>
 static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     constexpr int THREADS = RR_FLT_THREADS(4);
-    const rr_scan_geom G = rr_flt_geom<4, false>(ix);
+    const rr_scan_geom G = rr_flt_geom<4, PLANE>(ix);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -581,7 +581,8 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     float total = 0.f;
     for (int r = 0; r < reps + 1; ++r) {
         hipEventRecord(e0, st);
-        hipLaunchKernelGGL((rr_scan_flt<4, false, DBG>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
+        hipLaunchKernelGGL((rr_scan_flt<4, PLANE, DBG>), grid, block, 0, st,
+                           reinterpret_cast<const u32x4*>(PLANE ? (const void*)ix->d_shadow : (const void*)ix->d_matrix), G,
                            reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128);
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
@@ -611,6 +612,13 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
         case 16: *out_ms = rr_debug_time_flt<16>(ix, st, reps); break;
         case 31: *out_ms = rr_debug_time_flt<31>(ix, st, reps); break;
         case 32: *out_ms = rr_debug_time_flt<32>(ix, st, reps); break;
+        // + 64: the same over the bf16 filter plane (a batched search must have built it)
+        case 64: case 65: case 80: case 95: case 79:
+            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
+            *out_ms = dbg == 64 ? rr_debug_time_flt<0, true>(ix, st, reps) : dbg == 65 ? rr_debug_time_flt<1, true>(ix, st, reps)
+                    : dbg == 80 ? rr_debug_time_flt<16, true>(ix, st, reps) : dbg == 79 ? rr_debug_time_flt<15, true>(ix, st, reps)
+                    : rr_debug_time_flt<31, true>(ix, st, reps);
+            break;
         default: RR_REQUIRE(false, "unknown ablation %d", dbg);
     }
     RR_HIP_TRY(hipGetLastError());
