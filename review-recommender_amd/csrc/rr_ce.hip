@@ -32,6 +32,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
 #define CE_H 384
 #define CE_HEADS 12
@@ -192,20 +193,37 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
 
     // C layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     if constexpr (EPI != CE_EPI_RES_LN) {
+        // bias (+ GELU), then the wave's TM x TN sub-tile goes through its own LDS region so that it leaves as
+        // 16-byte row pieces (TN * 2 / 16 per row) instead of 2-byte stores: neighbouring columns sit in
+        // neighbouring lanes, so lane pairs first exchange one value and write packed bf16 pairs.
+        constexpr int SLD = TN + 8;                                        // staging row: TN bf16 + 16 B pad
+        unsigned short* stage = reinterpret_cast<unsigned short*>(ce_smem) + wave * (TM * SLD);
+        const int odd = lane & 1;
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int col = col0 + wn * TN + j * 32 + r32;
-                const float bv = bias[col];
+                const float bv = bias[col0 + wn * TN + j * 32 + r32];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int64_t row = row0 + wm * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    float v = acc[i][j][e] + bv;
-                    if (EPI == CE_EPI_GELU) v = ce_gelu(v);
-                    if (row < M) outb[row * N + col] = ce_bf16_bits(v);
+                for (int e = 0; e < 16; e += 2) {
+                    float v0 = acc[i][j][e] + bv, v1 = acc[i][j][e + 1] + bv;      // rows R(e), R(e) + 1, column r32
+                    if (EPI == CE_EPI_GELU) { v0 = ce_gelu(v0); v1 = ce_gelu(v1); }
+                    const float got = __shfl_xor(odd ? v0 : v1, 1, 64);
+                    // even lane: row R(e), columns (c, c + 1);  odd lane: row R(e) + 1, columns (c - 1, c)
+                    const bf16x2_t pk = odd ? bf16x2_t{(__bf16)got, (__bf16)v1} : bf16x2_t{(__bf16)v0, (__bf16)got};
+                    const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh + odd;
+                    *reinterpret_cast<unsigned int*>(stage + row * SLD + j * 32 + (r32 & ~1)) = __builtin_bit_cast(unsigned int, pk);
                 }
             }
+        __syncthreads();
+        constexpr int PIECES = TN / 8;                                     // 16-byte pieces per row of the sub-tile
+#pragma unroll
+        for (int u = 0; u < TM * PIECES / 64; ++u) {
+            const int idx = lane + 64 * u, row = idx / PIECES, pc = idx % PIECES;
+            const int64_t grow = row0 + wm * TM + row;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(stage + row * SLD + pc * 8);
+            if (grow < M) *reinterpret_cast<u32x4*>(outb + grow * N + col0 + wn * TN + pc * 8) = val;
+        }
     } else {
         // whole rows live in this workgroup (BN == N, WAVES_M == 1): x = acc + bias + residual, two-pass LayerNorm.
         // Row sums: in-lane over the wave's NB column blocks, a reduce-scatter butterfly over the 32 lanes of a
@@ -623,9 +641,9 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     static bool attr_set = false;
     if (!attr_set) {
         // dynamic LDS above 64 KB must be opted into per kernel
-        const int ldsB = (128 + 384) * CE_LDK * 2;
-        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
-        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
+        const int ldsB = (128 + 384) * CE_LDK * 2, ldsP = 8 * 64 * (96 + 8) * 2;
+        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP);
+        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP);
         hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
         hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512));
         attr_set = true;
@@ -636,15 +654,16 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
                        ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type, ce->eln_g, ce->eln_b,
                        ce->cfg.ln_eps, ce->h32, ce->hb);
     const size_t ldsB = (size_t)(128 + 384) * CE_LDK * 2;
+    const size_t ldsP = 8 * 64 * (96 + 8) * 2;          // plain epilogues stage eight 64 x 96 sub-tiles (> the K-tile buffers)
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
-        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 384)), dim3(512), ldsB, st, ce->hb, L.wqkv,
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 384)), dim3(512), ldsP, st, ce->hb, L.wqkv,
                            L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
         hipLaunchKernelGGL(ce_attention, dim3((unsigned)n_seqs, CE_HEADS), dim3(CE_ATT_THREADS), ce_attention_lds(smax_pad), st,
                            ce->qkv, d_cu_seqlens, ce->ctx, 0.17677669529663687f /* 1 / sqrt(32) */, smax_pad);
         hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(T, 128, 1)), dim3(512), ldsB, st, ce->ctx, L.wo, L.bo, T, CE_H,
                            CE_H, ce->hb, ce->h32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
-        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(T, 128, CE_FFN / 384)), dim3(512), ldsB, st, ce->hb, L.w1, L.b1, T,
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(T, 128, CE_FFN / 384)), dim3(512), ldsP, st, ce->hb, L.w1, L.b1, T,
                            CE_FFN, CE_H, ce->inter, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
         hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(T, 128, 1)), dim3(512), ldsB, st, ce->inter, L.w2, L.b2, T, CE_H,
                            CE_FFN, ce->hb, ce->h32, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);

@@ -612,12 +612,12 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
         case 16: *out_ms = rr_debug_time_flt<16>(ix, st, reps); break;
         case 31: *out_ms = rr_debug_time_flt<31>(ix, st, reps); break;
         case 32: *out_ms = rr_debug_time_flt<32>(ix, st, reps); break;
-        // + 64: the same over the bf16 filter plane (a batched search must have built it)
-        case 64: case 65: case 80: case 95: case 79:
+        // 64: the full kernel over the bf16 filter plane (a batched search must have built it).  The ablated
+        // variants are NOT built for the plane: `no epilogue` over the plane faulted on the GPU (r02: the ablations
+        // change register liveness around the asynchronous ring loads; only the variants above were ever validated)
+        case 64:
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
-            *out_ms = dbg == 64 ? rr_debug_time_flt<0, true>(ix, st, reps) : dbg == 65 ? rr_debug_time_flt<1, true>(ix, st, reps)
-                    : dbg == 80 ? rr_debug_time_flt<16, true>(ix, st, reps) : dbg == 79 ? rr_debug_time_flt<15, true>(ix, st, reps)
-                    : rr_debug_time_flt<31, true>(ix, st, reps);
+            *out_ms = rr_debug_time_flt<0, true>(ix, st, reps);
             break;
         default: RR_REQUIRE(false, "unknown ablation %d", dbg);
     }
