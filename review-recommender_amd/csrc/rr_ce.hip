@@ -139,8 +139,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    u32x4 pa[A_CHUNKS], pw[W_CHUNKS];
-    auto load_tile = [&](int kt) {
+    // K tiles travel global -> registers -> LDS with a prefetch distance of TWO tiles (two register sets): a
+    // workgroup is alone on its CU (two waves per SIMD, all in step behind the barriers), so a tile's loads need
+    // two compute phases, not one, to cover the L2 / HBM latency under load.
+    u32x4 pa0[A_CHUNKS], pw0[W_CHUNKS], pa1[A_CHUNKS], pw1[W_CHUNKS];
+    auto load_tile = [&](int kt, u32x4 (&pa)[A_CHUNKS], u32x4 (&pw)[W_CHUNKS]) {
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             const int c = tid + THREADS * i, r = c >> 3, p = c & 7;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
             pw[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)(col0 + r) * K + kt * 64 + p * 8);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const u32x4 (&pa)[A_CHUNKS], const u32x4 (&pw)[W_CHUNKS]) {
 #pragma unroll
         for (int i = 0; i < A_CHUNKS; ++i) {
             const int c = tid + THREADS * i, r = c >> 3, p = c & 7;
@@ -166,13 +169,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
             *reinterpret_cast<u32x4*>(Ws + r * CE_LDK + p * 8) = pw[i];
         }
     };
-
-    const int KT = K / 64;
-    load_tile(0);
-    for (int kt = 0; kt < KT; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < KT) load_tile(kt + 1);                                  // in flight under the MFMAs below
+    auto compute_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 af[MB], wf[NB];
@@ -188,8 +185,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
                 for (int j = 0; j < NB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+    };
+
+    // Barriers of the K loop: raw s_barrier behind an explicit LDS wait.  __syncthreads() would also wait vmcnt(0)
+    // (hipcc fences outstanding global loads at it), i.e. drain the prefetched tiles at every barrier.
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const int KT = K / 64;                           // even (K is 384 or 1536)
+    load_tile(0, pa0, pw0);
+    load_tile(1, pa1, pw1);
+    for (int kt = 0; kt < KT; kt += 2) {
+        store_tile(pa0, pw0);
+        lds_barrier();
+        if (kt + 2 < KT) load_tile(kt + 2, pa0, pw0);
+        compute_tile();
+        lds_barrier();
+        store_tile(pa1, pw1);
+        lds_barrier();
+        if (kt + 3 < KT) load_tile(kt + 3, pa1, pw1);
+        compute_tile();
+        lds_barrier();
     }
+    __syncthreads();
 
     // C layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     if constexpr (EPI != CE_EPI_RES_LN) {
@@ -541,6 +561,7 @@ extern "C" int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float
     RR_REQUIRE(out, "rr_ce_create: NULL out");
     *out = nullptr;
     RR_REQUIRE(cfg && t, "rr_ce_create: NULL argument");
+    static_assert(CE_H % 128 == 0 && CE_FFN % 128 == 0, "the GEMM loop takes K tiles of 64 in pairs");
     RR_REQUIRE(cfg->hidden == CE_H && cfg->n_heads == CE_HEADS && cfg->ffn == CE_FFN,
                "rr_ce_create: the kernels are built for hidden 384 / 12 heads x 32 / FFN 1536 (MiniLM-L6, bge-small); "
                "got hidden %d heads %d ffn %d", cfg->hidden, cfg->n_heads, cfg->ffn);
