@@ -58,6 +58,8 @@ struct rr_index {
     // bf16 filter plane of an fp32 matrix (rr_dense_flt.hip): every element rounded once to nearest even.  The batched
     // filter scan reads it instead of the fp32 rows (half the bytes per launch, the same approximate scores: the scan
     // rounds to bf16 anyway); candidates are rescored on the fp32 rows.  Built lazily, dropped by any write to the matrix.
+    float* d_flt_samp = nullptr;     // [<= RR_FLT_SAMP_CAP][RR_FLT_MAXQ] sampled tile maxima (store prefilter of rr_scan_flt)
+    float* d_flt_sigma = nullptr;    // [RR_FLT_MAXQ] per-query store threshold
     unsigned short* d_shadow = nullptr;
     bool shadow_valid = false;
     int32_t use_shadow = 1;

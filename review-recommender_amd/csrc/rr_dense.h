@@ -6,6 +6,7 @@
 #define RR_MAX_SCAN_WAVES 8192   // 2048 workgroups x 4 waves: upper bound of any resident grid
 #define RR_MFMA_MAXQ 64          // queries per exact matrix-core scan launch
 #define RR_FLT_MAXQ 128          // queries per filter-scan launch (rr_dense_flt.hip)
+#define RR_FLT_SAMP_CAP 8192      // sampled tiles of the store prefilter (rr_flt_sample)
 #define RR_FLT_NO_BOUND 1000     // rr_dense_chunk_flt: no finite row-norm bound, use the exact scans
 #define RR_FLT_SMALL 1001        // rr_dense_chunk_flt: too few tiles for the filter, use the VALU scans
 
@@ -63,7 +64,7 @@ size_t rr_x3_scratch_bytes();
 // `eps` (device, per query, may be null): the scan's scores are approximations within eps of the scores
 // the rescoring will produce; M-tiles are then opened down to tau - 2 eps and rows kept down to tau - eps.
 void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st,
-                             const float* eps = nullptr);
+                             const float* eps = nullptr, const float* sigma = nullptr);
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st);
 // Waves a kernel can keep resident on the device (occupancy x CUs x waves per workgroup).

@@ -768,7 +768,8 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
 __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
     rr_scan_geom G, const float* __restrict__ mmax, const uint32_t* __restrict__ smax, int pool,
     uint32_t* __restrict__ out_mtiles, int32_t* __restrict__ out_count, uint32_t* __restrict__ out_tau,
-    int32_t* __restrict__ fb, int32_t* __restrict__ dbg, const float* __restrict__ eps) {
+    int32_t* __restrict__ fb, int32_t* __restrict__ dbg, const float* __restrict__ eps,
+    const float* __restrict__ sigma) {
     __shared__ uint32_t cnt[2][3][16];
     __shared__ uint32_t counters[4];
     __shared__ uint32_t list2[RR_SEL_LCAP];
@@ -811,6 +812,10 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
             constexpr int U = 4;
             const float step = rr_flt_gap_step(eps, gridDim.x);
             const float openf = open <= 0x007FFFFFu ? -INFINITY : rr_key2f(open);   // (keys below key(-inf) are not scores)
+            // store prefilter of the scan: tiles whose maximum stayed below sigma[q] may not have been stored.  They
+            // cannot hold a candidate iff sigma[q] <= open; otherwise this query takes the exact fallback.  (Words of
+            // skipped tiles are stale: they can only open extra M-tiles, which the rescoring then discards.)
+            if (sigma && !(sigma[q] <= openf)) ok = false;
             const int n2i = (int)n2;                                       // (<= 4096 groups x tiles per group)
             for (int i0 = tid; i0 < n2i; i0 += U * RR_SEL_THREADS) {
                 int64_t tt[U];
@@ -962,10 +967,11 @@ size_t rr_x3_scratch_bytes() {
     return sizeof(uint32_t) * RR_FLT_MAXQ * RR_X3_MCAP + 4 * sizeof(int32_t) * RR_FLT_MAXQ +
            sizeof(float) * (size_t)RR_FLT_MAXQ * RR_X3_MCAP * 16;
 }
-void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st, const float* eps) {
+void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st, const float* eps,
+                             const float* sigma) {
     const rr_x3_scratch s = rr_x3_scratch_of(ix);
     hipLaunchKernelGGL(rr_select_mtiles, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_gmax, ix->d_smax, pool,
-                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps);
+                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps, sigma);
 }
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st) {
@@ -1007,6 +1013,10 @@ static int rr_ensure_scratch(rr_index* ix, int nq) {
     // tile / group maxima: up to RR_FLT_MAXQ queries per launch (x4: per-M-tile maxima of the matrix-core scans)
     const size_t nm = nq >= RR_MFMA_MAXQ ? RR_FLT_MAXQ : nq;
     RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * nm * n_tiles * 4));
+    // rr_scan_flt's store prefilter leaves the words of skipped tiles as they were: start from "-inf, no gaps" so that
+    // a never-written word cannot open anything (stale words of earlier launches can only add rescoring work)
+    RR_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->d_gmax, 0x0000FF80, nm * n_tiles * 4, nullptr));
+    RR_HIP_TRY(hipStreamSynchronize(nullptr));
     RR_HIP_TRY(hipMalloc(&ix->d_smax, sizeof(uint32_t) * nm * groups_cap));
     ix->scratch_q = nq;
     return RR_OK;

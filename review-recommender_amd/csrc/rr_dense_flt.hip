@@ -133,16 +133,20 @@ __global__ __launch_bounds__(256) void rr_row_norm_max(const void* __restrict__ 
 template <int NQ2, bool A_BF16, int DBG = 0>
 __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 1 : 2)) void rr_scan_flt(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [32*NQ2][48] units
-    float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq) {
+    float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq,
+    const float* __restrict__ sigma,      // [32*NQ2] store prefilter (null: every tile word is stored), see rr_flt_sample
+    uint32_t* __restrict__ dummy) {       // [n_waves][32*NQ2] lines that absorb the skipped stores
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
     constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
     constexpr int SEGS = A_BF16 ? 1 : 2;              // ring segments (24 units per lane) per 32-row M-tile
     constexpr int STEPS = A_BF16 ? 24 : 12;           // K-steps (16 dims) per ring segment
     __shared__ u32x4 qs[QN * RR_FLT_QSTRIDE];
+    __shared__ float sg[QN];
     const int tid = threadIdx.x;
     for (int i = tid; i < QN * RR_X3_UNITS; i += THREADS)
         qs[(i / RR_X3_UNITS) * RR_FLT_QSTRIDE + (i % RR_X3_UNITS)] = plane[i];
+    for (int i = tid; i < QN; i += THREADS) sg[i] = sigma ? sigma[i] : -INFINITY;
     __syncthreads();
 
     const int lane = tid & 63;
@@ -178,6 +182,13 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     int qlane = c * RR_FLT_QSTRIDE + h;               // 16-byte unit index into qs: + 32 t * QSTRIDE + 2 * kk
     float gm[NQ2];                                    // running maximum of the current group (sub-run of tiles)
     uint32_t pend[NQ2];                               // packed maxima of the 32-row tile just finished, stored one tile late
+    // Store prefilter: the word of (tile, 32-query group j) is only ever read if some query of the group can have a
+    // candidate in the tile, i.e. if its tile maximum reaches that query's sigma (a lower bound, minus the filter
+    // margin, of where its threshold will end up: rr_flt_sample).  ~90 % of the 128-byte lines fail that for all 32
+    // queries; their store goes to a line of this wave's own (L2-resident) instead -- the store COUNT stays what the
+    // hand-counted vmcnt waits assume, the bytes written back to HBM (what the stores cost) drop tenfold.
+    uint32_t pend_keep = 0xFFFFFFFFu;                 // bit j: the pending word of group j is wanted (wave-uniform)
+    uint32_t* const my_dummy = dummy ? dummy + (size_t)wave * QN : nullptr;
     const float step = rr_flt_gap_step(eps, nq);      // resolution of the 8-row gaps (half the smallest eps of the launch)
     const float inv_step = step > 0.f ? 0.9999f / step : 0.f;    // (0.9999: the decoded bound never rounds below the maximum)
 #pragma unroll
@@ -279,7 +290,9 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                     // into a saturated read stream.
                     if (p == 0 && s == STORE_STEP && !(DBG & 16)) {
                         const int64_t mprev = mt > m0 ? mt - 1 : mt;
-                        if (h == 0) reinterpret_cast<uint32_t*>(gmax)[mprev * QN + 32 * j + c] = pend[j];
+                        uint32_t* const line = (my_dummy && !((pend_keep >> j) & 1u)) ? my_dummy
+                                                                                       : reinterpret_cast<uint32_t*>(gmax) + mprev * QN;
+                        if (h == 0) line[32 * j + c] = pend[j];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -297,6 +310,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
         // lane (c, h), register 4g + i: row 8g + 4h + i of the M-tile, query 32t + c
         const int64_t rbase = mt * 32 + 4 * h;
         const bool full = mt * 32 + 32 <= G.n_rows;
+        uint32_t keep_now = 0u;
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
             // maxima of the four 8-row M-tiles (rows 8g .. 8g + 7 = registers 4g .. 4g + 3 of both k halves)
@@ -319,6 +333,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
             // max_up - steps(code) * step is an upper bound of the M-tile's maximum.
             const float m32 = fmaxf(fmaxf(m8[0], m8[1]), fmaxf(m8[2], m8[3]));
             gm[t] = fmaxf(gm[t], m32);
+            keep_now |= (__ballot(m32 >= sg[32 * t + c]) != 0ull ? 1u : 0u) << t;
             const uint32_t b = __float_as_uint(m32);
             uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);           // toward +inf; +-inf stay
 #pragma unroll
@@ -333,6 +348,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
             }
             pend[t] = word;
         }
+        pend_keep = keep_now;
         {   // group k of the wave = tiles [t0 + k Cg, t0 + (k + 1) Cg) of its run.  Its maximum is stored at once:
             // the next ring wait then covers a fresh store and stalls (~2 us), once per ~19 tiles.
             const int in_run = (int)((mt >> 1) - t0), cg = (int)G.tiles_per_group;
@@ -355,9 +371,87 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
             for (int t = 0; t < NQ2; ++t) smax[(wave * G.gpw + k) * QN + 32 * t + c] = 0u;
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
-            reinterpret_cast<uint32_t*>(gmax)[(m1 - 1) * QN + 32 * t + c] = pend[t];
+            if (!my_dummy || ((pend_keep >> t) & 1u)) reinterpret_cast<uint32_t*>(gmax)[(m1 - 1) * QN + 32 * t + c] = pend[t];
         }
     }
+}
+
+// ------------------------------------------------------------------ store prefilter: sampled thresholds
+// Every `stride`-th 32-row tile of the bf16 matrix / plane is scored against the launch's query planes (the same bf16
+// products as the scan, natural A loads: one wave per sampled tile, 24 K-steps x NQ2 MFMAs) and its maximum per query
+// kept: samp[tile][query].  Planes are in the scan's LDS layout and K order (RR_X3_ORDER_WIDE_BF16: position
+// 16 v + 8 h + j of a 32-dim block holds dim 16 h + 8 v + j), so lane half h of K-step s = 2 b + v multiplies the
+// row's dims 32 b + 16 h + 8 v .. + 7.
+template <int NQ2>
+__global__ __launch_bounds__(256, 1) void rr_flt_sample(const u32x4* __restrict__ mat, const u32x4* __restrict__ plane,
+                                                        int stride, int n_samp, float* __restrict__ samp) {
+    constexpr int QN = 32 * NQ2;
+    __shared__ u32x4 qs[QN * RR_FLT_QSTRIDE];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < QN * RR_X3_UNITS; i += 256)
+        qs[(i / RR_X3_UNITS) * RR_FLT_QSTRIDE + (i % RR_X3_UNITS)] = plane[i];
+    __syncthreads();
+    const int lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int total = gridDim.x * 4;
+    for (int ti = blockIdx.x * 4 + (tid >> 6); ti < n_samp; ti += total) {
+        const int64_t tile = (int64_t)ti * stride + stride / 2;           // a full tile: the host keeps the last one out
+        const u32x4* p = mat + (tile * 32 + c) * 48;
+        u32x4 a[24];
+#pragma unroll
+        for (int s = 0; s < 24; ++s) a[s] = p[4 * (s >> 1) + 2 * h + (s & 1)];
+        f32x16 acc[NQ2];
+#pragma unroll
+        for (int t = 0; t < NQ2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 24; ++s)
+#pragma unroll
+            for (int t = 0; t < NQ2; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s]),
+                                                                 __builtin_bit_cast(bf16x8, qs[(32 * t + c) * RR_FLT_QSTRIDE + 2 * s + h]),
+                                                                 acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NQ2; ++t) {
+            float m = acc[t][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) m = fmaxf(m, acc[t][e]);
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            if (h == 0) samp[(int64_t)ti * QN + 32 * t + c] = m;
+        }
+    }
+}
+
+// sigma[q] = (m-th largest sampled tile maximum of query q) - 2.05 eps[q]; slots past nq never keep a line (+inf);
+// a query without a finite bound keeps everything (-inf).  One workgroup per query slot, bisection over the
+// ordered keys (32 block-wide counts).
+__global__ __launch_bounds__(256) void rr_flt_sigma(const float* __restrict__ samp, int n_samp, int qn, int nq, int m,
+                                                    const float* __restrict__ eps, float* __restrict__ sigma) {
+    __shared__ uint32_t keys[RR_FLT_SAMP_CAP];
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, q = blockIdx.x;
+    if (q >= nq) { if (tid == 0) sigma[q] = INFINITY; return; }
+    const float e = eps[q];
+    if (n_samp < m || !(e >= 0.f && e < 3.0e38f)) { if (tid == 0) sigma[q] = -INFINITY; return; }
+    for (int i = tid; i < n_samp; i += 256) {
+        const float v = samp[(int64_t)i * qn + q];
+        keys[i] = v == v ? rr_f2key(v) : 0u;
+    }
+    __syncthreads();
+    uint32_t best = 0u;                                // largest key with count(keys >= key) >= m
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = best | (1u << bit);
+        int cnt = 0;
+        for (int i = tid; i < n_samp; i += 256) cnt += keys[i] >= cand ? 1 : 0;
+#pragma unroll
+        for (int mm = 32; mm >= 1; mm >>= 1) cnt += __shfl_xor(cnt, mm, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) wsum[tid >> 6] = cnt;
+        __syncthreads();
+        if (wsum[0] + wsum[1] + wsum[2] + wsum[3] >= m) best = cand;
+    }
+    if (tid == 0) sigma[q] = rr_key2f(best) - 2.05f * e;
 }
 
 // ------------------------------------------------------------------ exact rescoring
@@ -512,12 +606,38 @@ static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float*
     hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, X.eps, bounds,
                        SCAN_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
+    // Store prefilter (bf16 stream, >= 2M rows): a 1/64 tile sample gives every query sigma = its m-th largest sampled
+    // tile maximum - 2.05 eps.  The m-th largest of a 1/stride sample sits near rank m * stride of all rows; m leaves the
+    // probability that the sample alone holds m of the true top-`pool` rows (sigma above the final threshold: that
+    // query falls back to the exact pass) below 1e-9 (binomial(pool, 1/stride) tail).
+    const float* sigma = nullptr;
+    uint32_t* dummy = nullptr;
+    static const bool no_prefilter = getenv("RR_NO_PREFILTER") != nullptr;
+    const int64_t n_tiles32 = (G.n_rows + 31) / 32;
+    if (SCAN_BF16 && !no_prefilter && G.n_rows >= 2000000) {
+        const int stride = 64;
+        int64_t n_samp = (n_tiles32 - 1) / stride;
+        if (n_samp > RR_FLT_SAMP_CAP) n_samp = RR_FLT_SAMP_CAP;
+        const int m = 16 + (4 * pool + stride - 1) / stride;
+        if (!ix->d_flt_samp) {
+            RR_HIP_TRY(hipMalloc((void**)&ix->d_flt_samp, sizeof(float) * (size_t)RR_FLT_SAMP_CAP * RR_FLT_MAXQ));
+            RR_HIP_TRY(hipMalloc((void**)&ix->d_flt_sigma, sizeof(float) * RR_FLT_MAXQ));
+        }
+        hipLaunchKernelGGL((rr_flt_sample<NQ2>), dim3(256), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat),
+                           reinterpret_cast<const u32x4*>(plane), stride, (int)n_samp, ix->d_flt_samp);
+        hipLaunchKernelGGL(rr_flt_sigma, dim3(QN), dim3(256), 0, st, ix->d_flt_samp, (int)n_samp, QN, nq, m, X.eps,
+                           ix->d_flt_sigma);
+        sigma = ix->d_flt_sigma;
+        // the tile-maxima array is allocated for four words per (64-row tile, query); this scan uses two: the upper
+        // half holds the waves' dummy lines
+        dummy = reinterpret_cast<uint32_t*>(ix->d_gmax) + (size_t)2 * G.n_tiles * QN;
+    }
     const int slot = rr_scan_events_begin(ix, st);
     rr_scan_note(ix, 5, NQ2, nq, 1, SCAN_BF16 ? 2 : 4);
     hipLaunchKernelGGL((rr_scan_flt<NQ2, SCAN_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
-                       reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax, X.eps, nq);
+                       reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax, X.eps, nq, sigma, dummy);
     rr_scan_events_end(ix, slot, st);
-    rr_launch_select_mtiles(ix, G, nq, pool, st, X.eps);
+    rr_launch_select_mtiles(ix, G, nq, pool, st, X.eps, sigma);
     hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
                        X.mtiles, X.count, X.fb, X.sc);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st);
@@ -583,7 +703,8 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
         hipEventRecord(e0, st);
         hipLaunchKernelGGL((rr_scan_flt<4, PLANE, DBG>), grid, block, 0, st,
                            reinterpret_cast<const u32x4*>(PLANE ? (const void*)ix->d_shadow : (const void*)ix->d_matrix), G,
-                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128);
+                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128,
+                           (const float*)nullptr, (uint32_t*)nullptr);
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
         float ms = 0.f;

@@ -467,3 +467,38 @@ def test_bf16_filter_plane_of_an_fp32_index_gives_bitwise_the_same_answers(hip):
         assert np.array_equal(r1[0], rows_b[i]) and np.array_equal(s1[0].view(np.uint32), sc_b[i].view(np.uint32))
     check_against_oracle(V2, Q[:3], 150, index=ix)
     ix.close()
+
+
+def test_store_prefilter_of_the_filter_scan_stays_exact():
+    """>= 2M rows: the filter scan only writes back the tile words whose 32 queries can still matter (thresholds from a
+    1/64 tile sample).  (a) ordinary data: batched == single-query scan, bitwise, and the prefilter did not push any
+    query to the fallback; (b) adversarial layout -- the best rows of one query sit exactly in the sampled tiles, so
+    its sampled threshold overshoots: that query must take the exact fallback and still be right; (c) RR_NO_PREFILTER
+    semantics are the same answers (checked through (a) against the single-query scan, which has no prefilter)."""
+    import torch
+    n, pool = 2_200_000, 150
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    mat = torch.randn((n, 384), generator=g, device="cuda")
+    mat /= mat.norm(dim=1, keepdim=True)
+    Q = synth.unit_rows(40, 384, 4711)
+    # (b) 400 rows close to Q[3] placed in sampled tiles (tile 64 i + 32 -> rows (64 i + 32) * 32 + r)
+    q3 = torch.from_numpy(Q[3]).cuda()
+    gi = torch.Generator(device="cuda")
+    gi.manual_seed(5)
+    for i in range(400):
+        row = (64 * (i + 3) + 32) * 32 + (i % 32)
+        v = q3 * (0.9 - 0.0005 * i) + 0.3 * torch.randn(384, generator=gi, device="cuda") / 384 ** 0.5
+        mat[row] = v / v.norm()
+    ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=mat.data_ptr(), keepalive=mat)
+    rows, scores = ix.dense_topk(Q, pool)
+    assert _scan_info(ix)[0] == 5 and _scan_info(ix)[4] == 2
+    for i in (0, 1, 2, 17, 39):
+        r1, s1 = ix.dense_topk(Q[i:i + 1], pool)
+        assert np.array_equal(r1[0], rows[i]) and np.array_equal(s1[0].view(np.uint32), scores[i].view(np.uint32))
+    # query 3: served exactly whichever path it took
+    ref = (mat.double() @ q3.double()).cpu().numpy()
+    assert_topk_matches(rows[3], scores[3], ref, pool)
+    r1, s1 = ix.dense_topk(Q[3:4], pool)
+    _same_up_to_rounding(r1, s1, rows[3:4], scores[3:4])
+    ix.close()
