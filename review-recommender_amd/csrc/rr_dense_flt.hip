@@ -423,35 +423,31 @@ __global__ __launch_bounds__(256, 1) void rr_flt_sample(const u32x4* __restrict_
     }
 }
 
-// sigma[q] = (m-th largest sampled tile maximum of query q) - 2.05 eps[q]; slots past nq never keep a line (+inf);
-// a query without a finite bound keeps everything (-inf).  One workgroup per query slot, bisection over the
-// ordered keys (32 block-wide counts).
+// sigma[q] = (a lower bound of the m-th largest sampled tile maximum of query q) - 2.05 eps[q]; slots past nq never
+// keep a line (+inf); a query without a finite bound keeps everything (-inf).  One 256-thread workgroup per query
+// slot: every thread takes the maximum of its strided share of the samples (256 values, each a sampled tile maximum),
+// and the m-th largest of those 256 -- found by counting, no bisection -- is at most the m-th largest sample (m
+// distinct samples reach it) and sits close to it (m << 256: the top samples rarely share a thread).
+// `force` (timing experiments only, RR_FLT_SIGMA_FORCE): +1 = +inf for every query (no line is kept), -1 = -inf.
 __global__ __launch_bounds__(256) void rr_flt_sigma(const float* __restrict__ samp, int n_samp, int qn, int nq, int m,
-                                                    const float* __restrict__ eps, float* __restrict__ sigma) {
-    __shared__ uint32_t keys[RR_FLT_SAMP_CAP];
-    __shared__ int wsum[4];
+                                                    const float* __restrict__ eps, float* __restrict__ sigma, int force) {
+    __shared__ uint32_t tmax[256];
     const int tid = threadIdx.x, q = blockIdx.x;
-    if (q >= nq) { if (tid == 0) sigma[q] = INFINITY; return; }
+    if (q >= nq || force > 0) { if (tid == 0) sigma[q] = INFINITY; return; }
     const float e = eps[q];
-    if (n_samp < m || !(e >= 0.f && e < 3.0e38f)) { if (tid == 0) sigma[q] = -INFINITY; return; }
-    for (int i = tid; i < n_samp; i += 256) {
-        const float v = samp[(int64_t)i * qn + q];
-        keys[i] = v == v ? rr_f2key(v) : 0u;
-    }
+    if (n_samp < 256 || m > 128 || force < 0 || !(e >= 0.f && e < 3.0e38f)) { if (tid == 0) sigma[q] = -INFINITY; return; }
+    float best = -INFINITY;
+    for (int i = tid; i < n_samp; i += 256) best = fmaxf(best, samp[(int64_t)i * qn + q]);    // (fmaxf drops NaN)
+    const uint32_t mine = rr_f2key(best);
+    tmax[tid] = mine;
     __syncthreads();
-    uint32_t best = 0u;                                // largest key with count(keys >= key) >= m
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t cand = best | (1u << bit);
-        int cnt = 0;
-        for (int i = tid; i < n_samp; i += 256) cnt += keys[i] >= cand ? 1 : 0;
-#pragma unroll
-        for (int mm = 32; mm >= 1; mm >>= 1) cnt += __shfl_xor(cnt, mm, 64);
-        __syncthreads();
-        if ((tid & 63) == 0) wsum[tid >> 6] = cnt;
-        __syncthreads();
-        if (wsum[0] + wsum[1] + wsum[2] + wsum[3] >= m) best = cand;
+    int greater = 0, geq = 0;
+    for (int i = 0; i < 256; ++i) {
+        const uint32_t o = tmax[i];
+        greater += o > mine ? 1 : 0;
+        geq += o >= mine ? 1 : 0;
     }
-    if (tid == 0) sigma[q] = rr_key2f(best) - 2.05f * e;
+    if (greater < m && m <= geq) sigma[q] = rr_key2f(mine) - 2.05f * e;      // (threads with equal keys write the same value)
 }
 
 // ------------------------------------------------------------------ exact rescoring
@@ -625,8 +621,9 @@ static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float*
         }
         hipLaunchKernelGGL((rr_flt_sample<NQ2>), dim3(256), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat),
                            reinterpret_cast<const u32x4*>(plane), stride, (int)n_samp, ix->d_flt_samp);
+        static const int force = getenv("RR_FLT_SIGMA_FORCE") ? atoi(getenv("RR_FLT_SIGMA_FORCE")) : 0;
         hipLaunchKernelGGL(rr_flt_sigma, dim3(QN), dim3(256), 0, st, ix->d_flt_samp, (int)n_samp, QN, nq, m, X.eps,
-                           ix->d_flt_sigma);
+                           ix->d_flt_sigma, force);
         sigma = ix->d_flt_sigma;
         // the tile-maxima array is allocated for four words per (64-row tile, query); this scan uses two: the upper
         // half holds the waves' dummy lines

@@ -500,5 +500,6 @@ def test_store_prefilter_of_the_filter_scan_stays_exact():
     ref = (mat.double() @ q3.double()).cpu().numpy()
     assert_topk_matches(rows[3], scores[3], ref, pool)
     r1, s1 = ix.dense_topk(Q[3:4], pool)
-    _same_up_to_rounding(r1, s1, rows[3:4], scores[3:4])
+    assert_topk_matches(r1[0], s1[0], ref, pool)
+    np.testing.assert_allclose(s1[0], scores[3], atol=2e-6, rtol=0)      # scores ~0.95: chain vs split-operand rounding
     ix.close()
