@@ -185,9 +185,11 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     // Store prefilter: the word of (tile, 32-query group j) is only ever read if some query of the group can have a
     // candidate in the tile, i.e. if its tile maximum reaches that query's sigma (a lower bound, minus the filter
     // margin, of where its threshold will end up: rr_flt_sample).  ~90 % of the 128-byte lines fail that for all 32
-    // queries; their store goes to a line of this wave's own (L2-resident) instead -- the store COUNT stays what the
-    // hand-counted vmcnt waits assume, the bytes written back to HBM (what the stores cost) drop tenfold.
+    // queries; in place of their store the wave issues a load of a line of its own (cache-resident) -- the COUNT of
+    // vector-memory operations stays what the hand-counted vmcnt waits assume, the bytes written back to HBM (what the
+    // stores cost) drop with the lines skipped.
     uint32_t pend_keep = 0xFFFFFFFFu;                 // bit j: the pending word of group j is wanted (wave-uniform)
+    uint32_t junk = 0u;                               // destination of the loads that stand in for skipped stores
     uint32_t* const my_dummy = dummy ? dummy + (size_t)wave * QN : nullptr;
     const float step = rr_flt_gap_step(eps, nq);      // resolution of the 8-row gaps (half the smallest eps of the launch)
     const float inv_step = step > 0.f ? 0.9999f / step : 0.f;    // (0.9999: the decoded bound never rounds below the maximum)
@@ -290,9 +292,16 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                     // into a saturated read stream.
                     if (p == 0 && s == STORE_STEP && !(DBG & 16)) {
                         const int64_t mprev = mt > m0 ? mt - 1 : mt;
-                        uint32_t* const line = (my_dummy && !((pend_keep >> j) & 1u)) ? my_dummy
-                                                                                       : reinterpret_cast<uint32_t*>(gmax) + mprev * QN;
-                        if (h == 0) line[32 * j + c] = pend[j];
+                        if (my_dummy && !((pend_keep >> j) & 1u)) {
+                            // skipped line: a LOAD of this wave's own (cache-resident) line keeps the count of vector-memory
+                            // operations in flight that the ring waits assume; a store to such a line still went out to
+                            // HBM (PMC WRITE_SIZE unchanged at 165 MB per launch: full-line writes are streamed through)
+                            // (`junk` is one register that stays live over the whole scan -- "+v" here, touched again behind
+                            //  the final vmcnt(0) -- so nothing else can be allocated to it while such a load is in flight)
+                            asm volatile("global_load_dword %0, %1, off" : "+v"(junk) : "v"(my_dummy + lane) : "memory");
+                        } else if (h == 0) {
+                            reinterpret_cast<uint32_t*>(gmax)[mprev * QN + 32 * j + c] = pend[j];
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -363,6 +372,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
+    asm volatile("" :: "v"(junk));
     if (h == 0) {
         // groups of this wave that hold no tile (a short last run): key 0 = "nothing here"
         const int cg = (int)G.tiles_per_group;
@@ -383,42 +393,46 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
 // 16 v + 8 h + j of a 32-dim block holds dim 16 h + 8 v + j), so lane half h of K-step s = 2 b + v multiplies the
 // row's dims 32 b + 16 h + 8 v .. + 7.
 template <int NQ2>
-__global__ __launch_bounds__(256, 1) void rr_flt_sample(const u32x4* __restrict__ mat, const u32x4* __restrict__ plane,
+__global__ __launch_bounds__(512, 1) void rr_flt_sample(const u32x4* __restrict__ mat, const u32x4* __restrict__ plane,
                                                         int stride, int n_samp, float* __restrict__ samp) {
     constexpr int QN = 32 * NQ2;
+    constexpr int TQ = NQ2 >= 2 ? NQ2 / 2 : 1;          // query tiles per wave: a sampled tile is shared by NQ2 / TQ waves,
+    constexpr int SPLIT = NQ2 / TQ;                     // so eight waves (two per SIMD) fit the register file and overlap
     __shared__ u32x4 qs[QN * RR_FLT_QSTRIDE];
     const int tid = threadIdx.x;
-    for (int i = tid; i < QN * RR_X3_UNITS; i += 256)
+    for (int i = tid; i < QN * RR_X3_UNITS; i += 512)
         qs[(i / RR_X3_UNITS) * RR_FLT_QSTRIDE + (i % RR_X3_UNITS)] = plane[i];
     __syncthreads();
     const int lane = tid & 63, c = lane & 31, h = lane >> 5;
-    const int total = gridDim.x * 4;
-    for (int ti = blockIdx.x * 4 + (tid >> 6); ti < n_samp; ti += total) {
+    const int gw = blockIdx.x * 8 + (tid >> 6);         // global wave
+    const int part = gw % SPLIT, t0 = part * TQ;        // this wave's query tiles t0 .. t0 + TQ - 1
+    const int total = gridDim.x * 8 / SPLIT;
+    for (int ti = gw / SPLIT; ti < n_samp; ti += total) {
         const int64_t tile = (int64_t)ti * stride + stride / 2;           // a full tile: the host keeps the last one out
         const u32x4* p = mat + (tile * 32 + c) * 48;
         u32x4 a[24];
 #pragma unroll
         for (int s = 0; s < 24; ++s) a[s] = p[4 * (s >> 1) + 2 * h + (s & 1)];
-        f32x16 acc[NQ2];
+        f32x16 acc[TQ];
 #pragma unroll
-        for (int t = 0; t < NQ2; ++t)
+        for (int t = 0; t < TQ; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 #pragma unroll
         for (int s = 0; s < 24; ++s)
 #pragma unroll
-            for (int t = 0; t < NQ2; ++t)
+            for (int t = 0; t < TQ; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[s]),
-                                                                 __builtin_bit_cast(bf16x8, qs[(32 * t + c) * RR_FLT_QSTRIDE + 2 * s + h]),
+                                                                 __builtin_bit_cast(bf16x8, qs[(32 * (t0 + t) + c) * RR_FLT_QSTRIDE + 2 * s + h]),
                                                                  acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < NQ2; ++t) {
+        for (int t = 0; t < TQ; ++t) {
             float m = acc[t][0];
 #pragma unroll
             for (int e = 1; e < 16; ++e) m = fmaxf(m, acc[t][e]);
             const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
             m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-            if (h == 0) samp[(int64_t)ti * QN + 32 * t + c] = m;
+            if (h == 0) samp[(int64_t)ti * QN + 32 * (t0 + t) + c] = m;
         }
     }
 }
@@ -619,7 +633,7 @@ static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float*
             RR_HIP_TRY(hipMalloc((void**)&ix->d_flt_samp, sizeof(float) * (size_t)RR_FLT_SAMP_CAP * RR_FLT_MAXQ));
             RR_HIP_TRY(hipMalloc((void**)&ix->d_flt_sigma, sizeof(float) * RR_FLT_MAXQ));
         }
-        hipLaunchKernelGGL((rr_flt_sample<NQ2>), dim3(256), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat),
+        hipLaunchKernelGGL((rr_flt_sample<NQ2>), dim3(256), dim3(512), 0, st, reinterpret_cast<const u32x4*>(scan_mat),
                            reinterpret_cast<const u32x4*>(plane), stride, (int)n_samp, ix->d_flt_samp);
         static const int force = getenv("RR_FLT_SIGMA_FORCE") ? atoi(getenv("RR_FLT_SIGMA_FORCE")) : 0;
         hipLaunchKernelGGL(rr_flt_sigma, dim3(QN), dim3(256), 0, st, ix->d_flt_samp, (int)n_samp, QN, nq, m, X.eps,
