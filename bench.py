@@ -291,9 +291,10 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes), for this kernel at this many queries per launch on 10M
         # rows; the same bytes-per-row ratio is applied to this run's rows.  null without such a summary.
         traffic = None
-        for tag in ("r02", "r01"):
+        # (r02: the 128-query scan over the bf16 filter plane with the store prefilter; r01: the same scan over fp32 rows)
+        for tag in (("r02",) if info["elem_bytes"] == 2 else ("r01",)):
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_scan_b{qpl}_10M.json")
-            if os.path.exists(pmc) and args.dtype == "f32" and info["elem_bytes"] == 4:
+            if os.path.exists(pmc) and args.dtype == "f32":
                 with open(pmc) as f:
                     m = json.load(f)
                 traffic = int(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"] * bytes_per_launch)

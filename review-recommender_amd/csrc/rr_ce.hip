@@ -342,7 +342,10 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(CE_ATT_THREADS, 2) void ce_attention(const unsigned short* __restrict__ qkv,
                                                                   const int32_t* __restrict__ cu,
-                                                                  unsigned short* __restrict__ ctx, float scale, int smax_pad) {
+                                                                  unsigned short* __restrict__ ctx, float scale, int smax_pad,
+                                                                  unsigned short* __restrict__ ctx_cls) {
+    // ctx_cls != null: LAST layer of a [CLS]-pooled output -- only query row 0 of every sequence is needed downstream
+    // (pooler / CLS embedding), so only q-block 0 is computed and its row 0 lands in the compact ctx_cls[sequence]
     const int VT_LD = smax_pad + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
     unsigned short* Ks = reinterpret_cast<unsigned short*>(ce_smem);          // [smax_pad][CE_KS_LD]
@@ -373,7 +376,8 @@ __global__ __launch_bounds__(CE_ATT_THREADS, 2) void ce_attention(const unsigned
     // softmax in base 2 with the 1/sqrt(d) scale folded in: p = exp2(c1 * s - c1 * max), streamed over chunks of
     // 128 keys with a running maximum (raw scores; c1 > 0) and running sums, the accumulators rescaled per chunk
     const float c1 = scale * 1.4426950408889634f;
-    for (int qb = wave; qb * 16 < S; qb += CE_ATT_THREADS / 64) {
+    const int q_limit = ctx_cls ? 1 : S;
+    for (int qb = wave; qb * 16 < q_limit; qb += CE_ATT_THREADS / 64) {
         // B operand of S^T = K Q^T: lane (q = c16, g) holds Q[q][8g .. 8g+7]
         int qrow = qb * 16 + c16;
         qrow = qrow < S ? qrow : S - 1;
@@ -447,8 +451,8 @@ __global__ __launch_bounds__(CE_ATT_THREADS, 2) void ce_attention(const unsigned
         for (int r = 0; r < 4; ++r) {
             const int q = qb * 16 + 4 * g + r;
             const float inv = 1.f / __shfl(l_run, 4 * g + r, 64);          // lane 4g + r holds the sum of query column 4g + r
-            if (q < S) {
-                unsigned short* dst = ctx + (int64_t)(t0 + q) * CE_H + head * CE_HD;
+            if (q < q_limit) {
+                unsigned short* dst = (ctx_cls ? ctx_cls + (int64_t)seq * CE_H : ctx + (int64_t)(t0 + q) * CE_H) + head * CE_HD;
                 dst[c16] = ce_bf16_bits(o0[r] * inv);
                 dst[16 + c16] = ce_bf16_bits(o1[r] * inv);
             }
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256) void ce_head(const float* __restrict__ h32, co
                                                int mode, float* __restrict__ out) {
     __shared__ float x[CE_H], pooled[CE_H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seq = blockIdx.x;
-    const float* src = h32 + (int64_t)cu[seq] * CE_H;
+    const float* src = h32 + (int64_t)(cu ? cu[seq] : seq) * CE_H;       // cu == null: h32 is compact, one row per sequence
     for (int c = tid; c < CE_H; c += 256) x[c] = src[c];
     __syncthreads();
     if (mode == 1) {                                       // RR_CE_OUT_CLS: last_hidden_state[:, 0]
@@ -485,6 +489,14 @@ __global__ __launch_bounds__(256) void ce_head(const float* __restrict__ h32, co
         s = ce_wave_sum(s);
         if (lane == 0) out[(int64_t)seq * n_labels + l] = s + bc[l];
     }
+}
+
+// compact residual rows for the [CLS]-only tail of the last layer: dst[seq] = h32[cu[seq]]
+__global__ __launch_bounds__(128) void ce_gather_cls(const float* __restrict__ h32, const int32_t* __restrict__ cu,
+                                                     float* __restrict__ dst) {
+    const int seq = blockIdx.x;
+    const float* src = h32 + (int64_t)cu[seq] * CE_H;
+    for (int c = threadIdx.x; c < CE_H; c += 128) dst[(int64_t)seq * CE_H + c] = src[c];
 }
 
 __global__ void ce_to_bf16(const float* __restrict__ src, unsigned short* __restrict__ dst, int64_t n) {
@@ -509,6 +521,10 @@ struct rr_ce {
     int64_t cap = 0;
     float* h32 = nullptr;
     unsigned short *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *inter = nullptr;
+    // compact [sequence] buffers of the last layer's [CLS]-only tail
+    int64_t cap_seqs = 0;
+    float* h32c = nullptr;
+    unsigned short *hbc = nullptr, *ctxc = nullptr, *interc = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::mutex mu;
@@ -550,6 +566,7 @@ extern "C" int rr_ce_destroy(rr_ce* ce) {
     delete[] ce->layers;
     hipFree(ce->wp); hipFree(ce->bp); hipFree(ce->wc); hipFree(ce->bc);
     hipFree(ce->h32); hipFree(ce->hb); hipFree(ce->qkv); hipFree(ce->ctx); hipFree(ce->inter);
+    hipFree(ce->h32c); hipFree(ce->hbc); hipFree(ce->ctxc); hipFree(ce->interc);
     if (ce->ev0) hipEventDestroy(ce->ev0);
     if (ce->ev1) hipEventDestroy(ce->ev1);
     delete ce;
@@ -641,6 +658,22 @@ static unsigned ce_grid(int M, int BM, int n_col_tiles) {
     return (unsigned)(((mt + 7) / 8) * 8 * n_col_tiles);
 }
 
+static int ce_reserve_seqs(rr_ce* ce, int64_t seqs) {
+    if (seqs <= ce->cap_seqs) return RR_OK;
+    RR_HIP_TRY(hipDeviceSynchronize());
+    hipFree(ce->h32c); hipFree(ce->hbc); hipFree(ce->ctxc); hipFree(ce->interc);
+    ce->h32c = nullptr; ce->hbc = ce->ctxc = ce->interc = nullptr;
+    ce->cap_seqs = 0;
+    const size_t n = (size_t)rr_round_up(seqs, 1024);
+    hipError_t e = hipMalloc((void**)&ce->h32c, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->hbc, n * CE_H * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->ctxc, n * CE_H * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->interc, n * CE_FFN * 2);
+    if (e != hipSuccess) { rr_set_error("rr_ce_forward: compact scratch for %lld sequences: %s", (long long)seqs, hipGetErrorString(e)); return RR_E_NOMEM; }
+    ce->cap_seqs = (int64_t)n;
+    return RR_OK;
+}
+
 static size_t ce_attention_lds(int smax_pad) { return (size_t)smax_pad * CE_KS_LD * 2 + (size_t)32 * (smax_pad + 8) * 2; }
 
 extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_type_ids,
@@ -656,6 +689,8 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     std::lock_guard<std::mutex> lk(ce->mu);
     RR_HIP_TRY(hipSetDevice(ce->device));
     int rc = ce_reserve(ce, n_tokens);
+    if (rc) return rc;
+    rc = ce_reserve_seqs(ce, n_seqs);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int T = (int)n_tokens;
@@ -678,21 +713,32 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     const size_t ldsP = 8 * 64 * (96 + 8) * 2;          // plain epilogues stage eight 64 x 96 sub-tiles (> the K-tile buffers)
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
+        // The last layer of a [CLS]-pooled output (logits, CLS embedding) needs keys and values of every token but
+        // only the [CLS] query row: attention runs for that row alone and everything behind it -- output projection,
+        // both LayerNorms, the FFN -- on one compact row per sequence instead of one per token.
+        const bool cls_tail = (l == ce->cfg.n_layers - 1) && mode != RR_CE_OUT_HIDDEN;
+        const int Mr = cls_tail ? n_seqs : T;                              // rows behind the attention
+        float* r32 = cls_tail ? ce->h32c : ce->h32;
+        unsigned short* rb = cls_tail ? ce->hbc : ce->hb;
+        unsigned short* rctx = cls_tail ? ce->ctxc : ce->ctx;
+        unsigned short* rint = cls_tail ? ce->interc : ce->inter;
         hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 384)), dim3(512), ldsP, st, ce->hb, L.wqkv,
                            L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
         hipLaunchKernelGGL(ce_attention, dim3((unsigned)n_seqs, CE_HEADS), dim3(CE_ATT_THREADS), ce_attention_lds(smax_pad), st,
-                           ce->qkv, d_cu_seqlens, ce->ctx, 0.17677669529663687f /* 1 / sqrt(32) */, smax_pad);
-        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(T, 128, 1)), dim3(512), ldsB, st, ce->ctx, L.wo, L.bo, T, CE_H,
-                           CE_H, ce->hb, ce->h32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
-        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(T, 128, CE_FFN / 384)), dim3(512), ldsP, st, ce->hb, L.w1, L.b1, T,
-                           CE_FFN, CE_H, ce->inter, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
-        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(T, 128, 1)), dim3(512), ldsB, st, ce->inter, L.w2, L.b2, T, CE_H,
-                           CE_FFN, ce->hb, ce->h32, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
+                           ce->qkv, d_cu_seqlens, ce->ctx, 0.17677669529663687f /* 1 / sqrt(32) */, smax_pad,
+                           cls_tail ? ce->ctxc : (unsigned short*)nullptr);
+        if (cls_tail) hipLaunchKernelGGL(ce_gather_cls, dim3((unsigned)n_seqs), dim3(128), 0, st, ce->h32, d_cu_seqlens, ce->h32c);
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rctx, L.wo, L.bo, Mr, CE_H,
+                           CE_H, rb, r32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(Mr, 128, CE_FFN / 384)), dim3(512), ldsP, st, rb, L.w1, L.b1, Mr,
+                           CE_FFN, CE_H, rint, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rint, L.w2, L.b2, Mr, CE_H,
+                           CE_FFN, rb, r32, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
     }
     if (mode == RR_CE_OUT_HIDDEN)
         RR_HIP_TRY(hipMemcpyAsync(d_out, ce->h32, sizeof(float) * (size_t)T * CE_H, hipMemcpyDeviceToDevice, st));
     else
-        hipLaunchKernelGGL(ce_head, dim3((unsigned)n_seqs), dim3(256), 0, st, ce->h32, d_cu_seqlens, ce->wp, ce->bp, ce->wc, ce->bc,
+        hipLaunchKernelGGL(ce_head, dim3((unsigned)n_seqs), dim3(256), 0, st, ce->h32c, (const int32_t*)nullptr, ce->wp, ce->bp, ce->wc, ce->bc,
                            ce->cfg.n_labels, mode, d_out);
     hipEventRecord(ce->ev1, st);
     ce->timed = true;
