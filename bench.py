@@ -263,6 +263,8 @@ def main():
     total_ms, launches = _scan_stats(index)
     info = _scan_info(index)
     per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
+    if os.environ.get("RR_BENCH_DEBUG"):
+        print("per-step ms:", np.round(per_step, 3).tolist(), file=sys.stderr, flush=True)
 
     # the HBM-bound end of the path: one query per matrix read (rr_scan_f32<6,1>), same shard
     q1 = q_dev[0][:1].contiguous()
@@ -321,6 +323,7 @@ def main():
             "ms_per_step_median": round(float(np.median(per_step)), 4),
             "ms_per_step_p10": round(float(np.percentile(per_step, 10)), 4),
             "ms_per_step_p90": round(float(np.percentile(per_step, 90)), 4),
+            "ms_per_step_max": round(float(per_step.max()), 4),
             "timed_region": "H2D queries + token ids -> K1 -> K2 -> [all-gather] -> K3 -> D2H rows/order/finals",
             "scan_ms_per_step": round(total_ms / max(args.steps, 1), 4),
             "config": {"workload": (f"{'hybrid BM25+dense alpha=0.5' if not args.no_bm25 else 'dense-only cosine'} "

@@ -149,10 +149,15 @@ class HybridSearcher:
         slot = self._stage_slots[self._stage_next % len(self._stage_slots)]
         self._stage_next += 1
         if slot["host"] is None or slot["host"].numel() < need:
-            cap = max(need, 4096)
-            slot["host"] = torch.empty(cap, dtype=torch.int32).pin_memory()
-            slot["dev"] = torch.empty(cap, dtype=torch.int32, device=self.device)
-            slot["event"] = torch.cuda.Event()
+            # (pinning host memory is slow and synchronises: every slot of the ring is sized at once, on first use)
+            cap = max(2 * need, 16384)
+            for sl in self._stage_slots:
+                if sl["host"] is None or sl["host"].numel() < need:
+                    if sl["event"] is not None:
+                        sl["event"].synchronize()
+                    sl["host"] = torch.empty(cap, dtype=torch.int32).pin_memory()
+                    sl["dev"] = torch.empty(cap, dtype=torch.int32, device=self.device)
+                    sl["event"] = torch.cuda.Event()
         else:
             slot["event"].synchronize()          # the copy that last used this pinned buffer has finished
         h = slot["host"].numpy()
