@@ -25,6 +25,8 @@
 //   ce_head          pooler (tanh) + classifier on the [CLS] rows, fp32
 // GEMM tiles: 32x32x16 bf16 MFMA, K-step 64 through LDS rows padded to 144 B (conflict-free ds_read_b128),
 // next K tile prefetched global -> registers under the MFMAs of the current one.
+#include <vector>
+
 #include "rr_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -333,6 +335,164 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
     }
 }
 
+// ------------------------------------------------------------------ fused FFN: LayerNorm(h + W2 gelu(W1 h + b1) + b2)
+// One kernel for intermediate.dense + GELU + output.dense + residual + LayerNorm, in TRANSPOSED form: the wave's 32
+// tokens sit on the MFMA columns (lanes) for the whole kernel.
+//   X^T[j][tok] = W1[j] . h[tok]      A operand = W1 rows of a 32-feature chunk (LDS), B operand = the tokens' bf16 rows,
+//                                     held in registers for the whole kernel (24 K-steps x 4 VGPRs, loaded once)
+//   out^T[n][tok] += W2[n][j] X^T[j][tok]   the 32 x 32 accumulator tile X^T (+ b1, GELU, -> bf16) IS the B operand of the
+//                                     second product as it sits (token on the lane, features in registers): no LDS round
+//                                     trip, no lane movement.  Its k order inside a 16-step is permuted (element jj of
+//                                     lane half h = feature 16 s + 8 (jj >> 2) + 4 h + (jj & 3)); W2 is stored with its
+//                                     columns permuted the same way once at load (rr_ce_create: w2p).
+// The 6 KB-per-token intermediate never leaves the CU, the whole FFN is one launch, and the LayerNorm statistics of a
+// token are sums over the registers of one lane pair (lane, lane ^ 32): no cross-wave reduction.
+// Workgroup = 4 waves x 32 tokens, one wave per SIMD (hb fragments 96 + out^T accumulators 192 registers per lane); W1 / W2
+// chunks (24 KB each) stream L2 -> registers -> LDS, double-buffered, one barrier per chunk; per chunk and wave 48 MFMAs
+// against 48 ds_read_b128.
+#define CE_FFN_TOK 128          // tokens per workgroup
+#define CE_FFN_CH 32            // intermediate features per chunk
+#define CE_W1_LD (CE_H + 8)     // LDS row of a W1 chunk: 384 bf16 + 16 B pad
+#define CE_W2_LD (CE_FFN_CH + 8)    // LDS row of a W2 chunk: 32 bf16 + 16 B pad
+#define CE_FFN_BUF (CE_FFN_CH * CE_W1_LD + CE_H * CE_W2_LD)     // bf16 elements per chunk buffer
+
+__global__ __launch_bounds__(256, 1) void ce_ffn_fused(
+    unsigned short* __restrict__ hb, float* __restrict__ h32, int M,
+    const unsigned short* __restrict__ W1, const float* __restrict__ b1,       // [1536][384], [1536]
+    const unsigned short* __restrict__ W2p, const float* __restrict__ b2,      // [384][1536] columns permuted, [384]
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
+    unsigned short* wbuf = reinterpret_cast<unsigned short*>(ce_smem);          // [2][CE_FFN_BUF]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    const int64_t tok0 = (int64_t)blockIdx.x * CE_FFN_TOK + wave * 32;
+    int64_t tok = tok0 + c;
+    const bool live = tok < M;
+    tok = live ? tok : M - 1;
+
+    // the tokens' rows as B fragments: lane (c, hh), K-step s holds hb[tok][16 s + 8 hh .. + 7]
+    bf16x8 hf[24];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) hf[s] = *reinterpret_cast<const bf16x8*>(hb + tok * CE_H + 16 * s + 8 * hh);
+
+    f32x16 acc[12];
+#pragma unroll
+    for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+
+    // chunk staging: W1 rows j0 .. j0+31 (32 x 768 B = 1536 pieces of 16 B), W2p columns j0 .. j0+31 of all 384 rows
+    // (384 x 64 B = 1536 pieces): 6 + 6 pieces per thread
+    u32x4 p1[6], p2[6];
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 256 * i;
+            p1[i] = *reinterpret_cast<const u32x4*>(W1 + (int64_t)(ch * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
+            p2[i] = *reinterpret_cast<const u32x4*>(W2p + (int64_t)(id >> 2) * CE_FFN + ch * CE_FFN_CH + (id & 3) * 8);
+        }
+    };
+    auto store_chunk = [&](unsigned short* buf) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(buf + (id / 48) * CE_W1_LD + (id % 48) * 8) = p1[i];
+            *reinterpret_cast<u32x4*>(buf + CE_FFN_CH * CE_W1_LD + (id >> 2) * CE_W2_LD + (id & 3) * 8) = p2[i];
+        }
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    constexpr int NCH = CE_FFN / CE_FFN_CH;          // 48 chunks
+    load_chunk(0);
+    store_chunk(wbuf);
+    lds_barrier();
+    for (int ch = 0; ch < NCH; ++ch) {
+        const unsigned short* w1c = wbuf + (ch & 1) * CE_FFN_BUF;
+        const unsigned short* w2c = w1c + CE_FFN_CH * CE_W1_LD;
+        if (ch + 1 < NCH) load_chunk(ch + 1);                              // in flight under this chunk's MFMAs
+        // ---- X^T = W1c . h^T  (one accumulator chain: a 32x32 MFMA's issue interval covers its own latency)
+        f32x16 x0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x0[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w1c + c * CE_W1_LD + 16 * s + 8 * hh);
+            x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, hf[s], x0, 0, 0, 0);
+        }
+        // ---- + b1, GELU, -> bf16: register e of lane half hh is feature (e & 3) + 8 (e >> 2) + 4 hh of the chunk
+        bf16x8 xb[2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + ch * CE_FFN_CH + 8 * g + 4 * hh);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = 4 * g + r;
+                const float v = ce_gelu(x0[e] + bv[r]);
+                xb[e >> 3][e & 7] = (__bf16)v;
+            }
+        }
+        // ---- out^T += W2c . X^T
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(w2c + (nb * 32 + c) * CE_W2_LD + 16 * s2 + 8 * hh);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s2], acc[nb], 0, 0, 0);
+            }
+        if (ch + 1 < NCH) store_chunk(wbuf + ((ch + 1) & 1) * CE_FFN_BUF);
+        lds_barrier();
+    }
+
+    // ---- + b2 + residual, LayerNorm over the token's 384 features (this lane: 192 of them, lane ^ 32 the others)
+    float sum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nb * 32 + 8 * g + 4 * hh;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + n);
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(h32 + tok * CE_H + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (acc[nb][4 * g + r] + bv[r]) + rv[r];
+                acc[nb][4 * g + r] = v;
+                sum += v;
+            }
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / CE_H);
+    float var = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float d = acc[nb][e] - mean; var += d * d; }
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = rsqrtf(var * (1.f / CE_H) + ln_eps);
+    if (live) {
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb * 32 + 8 * g + 4 * hh;
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(ln_g + n);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(ln_b + n);
+                f32x4 y;
+                bf16x4 yb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = (acc[nb][4 * g + r] - mean) * rstd * gv[r] + be[r];
+                    yb[r] = (__bf16)y[r];
+                }
+                *reinterpret_cast<f32x4*>(h32 + tok * CE_H + n) = y;
+                *reinterpret_cast<bf16x4*>(hb + tok * CE_H + n) = yb;
+            }
+    }
+}
+
 // ------------------------------------------------------------------ attention: one workgroup per (sequence, head)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define CE_KS_LD 40         // K rows in LDS: 32 bf16 + 8 pad = 80 B (conflict-free ds_read_b128 over 16 rows)
@@ -507,6 +667,7 @@ __global__ void ce_to_bf16(const float* __restrict__ src, unsigned short* __rest
 // ------------------------------------------------------------------ host side
 struct rr_ce_layer {
     unsigned short *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;      // bf16 [N][K]
+    unsigned short* w2p = nullptr;   // w2 with the columns of every 16-group in the fused FFN's accumulator-operand order
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
 };
@@ -559,7 +720,7 @@ extern "C" int rr_ce_destroy(rr_ce* ce) {
     if (ce->layers)
         for (int l = 0; l < ce->cfg.n_layers; ++l) {
             rr_ce_layer& L = ce->layers[l];
-            hipFree(L.wqkv); hipFree(L.wo); hipFree(L.w1); hipFree(L.w2);
+            hipFree(L.wqkv); hipFree(L.wo); hipFree(L.w1); hipFree(L.w2); hipFree(L.w2p);
             hipFree(L.bqkv); hipFree(L.bo); hipFree(L.b1); hipFree(L.b2);
             hipFree(L.ln1_g); hipFree(L.ln1_b); hipFree(L.ln2_g); hipFree(L.ln2_b);
         }
@@ -622,6 +783,17 @@ extern "C" int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float
         f32(&L.ln1_g, p[8], H);  f32(&L.ln1_b, p[9], H);
         alloc16(&L.w1, F * H);   b16(L.w1, p[10], F * H);  f32(&L.b1, p[11], F);
         alloc16(&L.w2, H * F);   b16(L.w2, p[12], H * F);  f32(&L.b2, p[13], H);
+        alloc16(&L.w2p, H * F);
+        if (!rc) {
+            // position 8 h + jj of a 16-group holds column 8 (jj >> 2) + 4 h + (jj & 3): quads (0, 2, 1, 3)
+            std::vector<float> perm(H * F);
+            for (size_t n = 0; n < H; ++n)
+                for (size_t j = 0; j < F; ++j) {
+                    const size_t q = (j >> 2) & 3, src = (j & ~(size_t)15) + 4 * (q == 1 ? 2 : q == 2 ? 1 : q) + (j & 3);
+                    perm[n * F + j] = p[12][n * F + src];
+                }
+            b16(L.w2p, perm.data(), H * F);
+        }
         f32(&L.ln2_g, p[14], H); f32(&L.ln2_b, p[15], H);
     }
     if (!rc && cfg->n_labels > 0) {
@@ -702,6 +874,7 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
         hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP);
         hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
         hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512));
+        hipFuncSetAttribute((const void*)ce_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CE_FFN_BUF * 2);
         attr_set = true;
     }
     const int smax_pad = (max_len + 31) & ~31;
@@ -711,6 +884,8 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
                        ce->cfg.ln_eps, ce->h32, ce->hb);
     const size_t ldsB = (size_t)(128 + 384) * CE_LDK * 2;
     const size_t ldsP = 8 * 64 * (96 + 8) * 2;          // plain epilogues stage eight 64 x 96 sub-tiles (> the K-tile buffers)
+    const size_t ldsF = (size_t)2 * CE_FFN_BUF * 2;     // fused FFN: two chunk buffers
+    static const bool unfused = getenv("RR_CE_UNFUSED") != nullptr;   // A/B: FFN as two GEMM launches
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
         // The last layer of a [CLS]-pooled output (logits, CLS embedding) needs keys and values of every token but
@@ -730,10 +905,15 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
         if (cls_tail) hipLaunchKernelGGL(ce_gather_cls, dim3((unsigned)n_seqs), dim3(128), 0, st, ce->h32, d_cu_seqlens, ce->h32c);
         hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rctx, L.wo, L.bo, Mr, CE_H,
                            CE_H, rb, r32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
-        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(Mr, 128, CE_FFN / 384)), dim3(512), ldsP, st, rb, L.w1, L.b1, Mr,
-                           CE_FFN, CE_H, rint, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
-        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rint, L.w2, L.b2, Mr, CE_H,
-                           CE_FFN, rb, r32, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
+        if (!unfused) {
+            hipLaunchKernelGGL(ce_ffn_fused, dim3((unsigned)((Mr + CE_FFN_TOK - 1) / CE_FFN_TOK)), dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1,
+                               L.w2p, L.b2, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
+        } else {
+            hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(Mr, 128, CE_FFN / 384)), dim3(512), ldsP, st, rb, L.w1, L.b1, Mr,
+                               CE_FFN, CE_H, rint, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
+            hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rint, L.w2, L.b2, Mr, CE_H,
+                               CE_FFN, rb, r32, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
+        }
     }
     if (mode == RR_CE_OUT_HIDDEN)
         RR_HIP_TRY(hipMemcpyAsync(d_out, ce->h32, sizeof(float) * (size_t)T * CE_H, hipMemcpyDeviceToDevice, st));
