@@ -381,21 +381,22 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
 
-    // chunk staging: W1 rows j0 .. j0+31 (32 x 768 B = 1536 pieces of 16 B), W2p columns j0 .. j0+31 of all 384 rows
-    // (384 x 64 B = 1536 pieces): 6 + 6 pieces per thread
-    u32x4 p1[6], p2[6];
-    auto load_chunk = [&](int ch) {
+    // chunk staging: W1 rows j0 .. j0+31 (32 x 768 B = 1536 pieces of 16 B) and W2p columns j0 .. j0+31 of all 384 rows
+    // (384 x 64 B = 1536 pieces), 6 + 6 pieces per thread, moved in two halves (3 + 3 pieces) so that only 24 staging
+    // registers are live at a time: the rest of the budget goes to the fragment pipeline below
+    u32x4 p1[3], p2[3];
+    auto load_half = [&](int ch, int half) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 256 * i;
+        for (int i = 0; i < 3; ++i) {
+            const int id = tid + 256 * (3 * half + i);
             p1[i] = *reinterpret_cast<const u32x4*>(W1 + (int64_t)(ch * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
             p2[i] = *reinterpret_cast<const u32x4*>(W2p + (int64_t)(id >> 2) * CE_FFN + ch * CE_FFN_CH + (id & 3) * 8);
         }
     };
-    auto store_chunk = [&](unsigned short* buf) {
+    auto store_half = [&](unsigned short* buf, int half) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 256 * i;
+        for (int i = 0; i < 3; ++i) {
+            const int id = tid + 256 * (3 * half + i);
             *reinterpret_cast<u32x4*>(buf + (id / 48) * CE_W1_LD + (id % 48) * 8) = p1[i];
             *reinterpret_cast<u32x4*>(buf + CE_FFN_CH * CE_W1_LD + (id >> 2) * CE_W2_LD + (id & 3) * 8) = p2[i];
         }
@@ -407,22 +408,34 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     };
 
     constexpr int NCH = CE_FFN / CE_FFN_CH;          // 48 chunks
-    load_chunk(0);
-    store_chunk(wbuf);
+    constexpr int DEPTH = 4;                         // A fragments in flight ahead of their MFMA: one wave per SIMD, so the
+                                                     // LDS latency (~100+ cycles against 32 per MFMA) is hidden by depth
+    load_half(0, 0); store_half(wbuf, 0);
+    load_half(0, 1); store_half(wbuf, 1);
     lds_barrier();
     for (int ch = 0; ch < NCH; ++ch) {
         const unsigned short* w1c = wbuf + (ch & 1) * CE_FFN_BUF;
         const unsigned short* w2c = w1c + CE_FFN_CH * CE_W1_LD;
-        if (ch + 1 < NCH) load_chunk(ch + 1);                              // in flight under this chunk's MFMAs
+        unsigned short* nxt = wbuf + ((ch + 1) & 1) * CE_FFN_BUF;
+        const bool more = ch + 1 < NCH;
+        if (more) load_half(ch + 1, 0);                                    // in flight under the first product
         // ---- X^T = W1c . h^T  (one accumulator chain: a 32x32 MFMA's issue interval covers its own latency)
         f32x16 x0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) x0[e] = 0.f;
+        {
+            const unsigned short* ap = w1c + c * CE_W1_LD + 8 * hh;
+            bf16x8 af[DEPTH];
 #pragma unroll
-        for (int s = 0; s < 24; ++s) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(w1c + c * CE_W1_LD + 16 * s + 8 * hh);
-            x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, hf[s], x0, 0, 0, 0);
+            for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + 16 * i);
+#pragma unroll
+            for (int s = 0; s < 24; ++s) {
+                x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], x0, 0, 0, 0);
+                if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if (more) { store_half(nxt, 0); load_half(ch + 1, 1); }            // second half under the GELU and the second product
         // ---- + b1, GELU, -> bf16: register e of lane half hh is feature (e & 3) + 8 (e >> 2) + 4 hh of the chunk
         bf16x8 xb[2];
 #pragma unroll
@@ -436,14 +449,20 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
             }
         }
         // ---- out^T += W2c . X^T
+        {
+            const unsigned short* ap = w2c + c * CE_W2_LD + 8 * hh;
+            auto frag = [&](int i) { return *reinterpret_cast<const bf16x8*>(ap + (i >> 1) * 32 * CE_W2_LD + 16 * (i & 1)); };
+            bf16x8 af[DEPTH];
 #pragma unroll
-        for (int nb = 0; nb < 12; ++nb)
+            for (int i = 0; i < DEPTH; ++i) af[i] = frag(i);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(w2c + (nb * 32 + c) * CE_W2_LD + 16 * s2 + 8 * hh);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s2], acc[nb], 0, 0, 0);
+            for (int i = 0; i < 24; ++i) {                                  // i = 2 nb + s2
+                acc[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i % DEPTH], xb[i & 1], acc[i >> 1], 0, 0, 0);
+                if (i + DEPTH < 24) af[i % DEPTH] = frag(i + DEPTH);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        if (ch + 1 < NCH) store_chunk(wbuf + ((ch + 1) & 1) * CE_FFN_BUF);
+        }
+        if (more) store_half(nxt, 1);
         lds_barrier();
     }
 
