@@ -44,16 +44,35 @@ def parse_args(argv=None):
     ap.add_argument("--data-dir", type=str, default="data/processed", help="directory with the three artefacts")
     ap.add_argument("--qvec-npy", type=str, default="", help=".npy with the query embedding (offline use)")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--emb-model-dir", type=str, default=os.environ.get("EMB_MODEL_DIR", ""),
+                    help="local Hugging Face directory of the query encoder (model.safetensors | pytorch_model.bin, vocab.txt): "
+                         "runs on the GPU (csrc/rr_ce.hip); nothing is fetched")
+    ap.add_argument("--rerank-model-dir", type=str, default=os.environ.get("RERANK_MODEL_DIR", ""),
+                    help="local Hugging Face directory of the cross-encoder reranker, likewise")
     return ap.parse_args(argv)
 
 
-def _load_encoders():
+def _load_encoders(args=None):
+    """Query encoder and reranker: local model directories on the GPU when given (--emb-model-dir / --rerank-model-dir),
+    else sentence-transformers by model name as the reference does (app/test.py:91-104) when that package and its
+    weights are present.  A reranker that cannot be loaded degrades to zeros with the reference's warning."""
     enc = ce = None
+    if args is not None and (args.emb_model_dir or args.rerank_model_dir):
+        from .cross_encoder import CrossEncoder, QueryEncoder
+        if args.emb_model_dir:
+            enc = QueryEncoder.from_pretrained_dir(args.emb_model_dir, device=args.device)
+        if args.rerank_model_dir:
+            try:
+                ce = CrossEncoder.from_pretrained_dir(args.rerank_model_dir, device=args.device)
+            except Exception as e:   # app/test.py:220-222
+                print(f"[warn] cross-encoder load failed: {e}; skipping reranker.", flush=True)
+        if enc is not None:
+            return enc, ce
     try:
         from sentence_transformers import CrossEncoder, SentenceTransformer
         enc = SentenceTransformer(EMB_MODEL)
         try:
-            ce = CrossEncoder(RERANK_MODEL)
+            ce = ce or CrossEncoder(RERANK_MODEL)
         except Exception as e:   # app/test.py:220-222
             print(f"[warn] cross-encoder load failed: {e}; skipping reranker.", flush=True)
     except Exception:
@@ -66,7 +85,7 @@ def main(argv=None) -> int:
     from .artifacts import ArtifactError
     from .engine import SearchEngine, cli_rows
     qvec = np.load(args.qvec_npy).astype(np.float32).reshape(-1) if args.qvec_npy else None
-    enc, ce = (None, None) if qvec is not None else _load_encoders()
+    enc, ce = _load_encoders(args) if (qvec is None or args.rerank_model_dir) else (None, None)
     if qvec is None and enc is None:
         raise SystemExit(f"[ERR] loading/encoding with {EMB_MODEL} failed: sentence-transformers or its weights "
                          "are unavailable; pass --qvec-npy")          # app/test.py:234-235

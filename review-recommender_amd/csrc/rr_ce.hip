@@ -412,13 +412,13 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
                                                      // LDS latency (~100+ cycles against 32 per MFMA) is hidden by depth
     load_half(0, 0); store_half(wbuf, 0);
     load_half(0, 1); store_half(wbuf, 1);
+    load_half(1, 0);                                                       // first half of chunk 1: in flight over the barrier
     lds_barrier();
     for (int ch = 0; ch < NCH; ++ch) {
         const unsigned short* w1c = wbuf + (ch & 1) * CE_FFN_BUF;
         const unsigned short* w2c = w1c + CE_FFN_CH * CE_W1_LD;
         unsigned short* nxt = wbuf + ((ch + 1) & 1) * CE_FFN_BUF;
-        const bool more = ch + 1 < NCH;
-        if (more) load_half(ch + 1, 0);                                    // in flight under the first product
+        const bool more = ch + 1 < NCH;                                    // (its first half was requested a chunk ago)
         // ---- X^T = W1c . h^T  (one accumulator chain: a 32x32 MFMA's issue interval covers its own latency)
         f32x16 x0;
 #pragma unroll
@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
             }
         }
         if (more) store_half(nxt, 1);
+        if (ch + 2 < NCH) load_half(ch + 2, 0);                            // in flight over the barrier and the next first product
         lds_barrier();
     }
 

@@ -174,3 +174,62 @@ def test_run_search_reranks_with_the_real_kernel_end_to_end():
     assert np.abs(g["_final"].values - c.loc[g.index, "_final"].values).max() < cfg["w_rerank"] * tol + 1e-5
     top_want = set(want["sku"][:10])
     assert len(top_want & set(got["sku"])) >= 8
+
+
+def write_model_dir(path, sd, vocab_words, with_config=True):
+    """A local Hugging Face style model directory: model.safetensors + vocab.txt (+ config.json)."""
+    import json
+    from safetensors.numpy import save_file
+    path.mkdir(parents=True, exist_ok=True)
+    save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, str(path / "model.safetensors"))
+    (path / "vocab.txt").write_text("\n".join(vocab_words) + "\n", encoding="utf-8")
+    if with_config:
+        (path / "config.json").write_text(json.dumps({"layer_norm_eps": 1e-12, "hidden_size": 384}))
+
+
+def test_cli_runs_offline_from_local_model_directories(tmp_path, capsys):
+    """app/test.py end to end with BOTH models on the GPU, loaded from local directories (nothing fetched): the query is
+    encoded by QueryEncoder, the top rerank_k candidates rescored by CrossEncoder, JSON rows against the oracle fed the
+    numpy oracle's embedding and scores."""
+    import json
+    from oracle.pipeline import cli_rows
+    from review_recommender_amd import artifacts
+    from review_recommender_amd.cli import main
+    tok = vocab_tokenizer()
+    words = sorted(tok.vocab, key=tok.vocab.get)
+    sd_ce = synth.bert_state_dict(41, n_layers=6, n_labels=1, vocab=len(words))
+    sd_q = synth.bert_state_dict(42, n_layers=12, n_labels=0, prefix="", vocab=len(words))
+    write_model_dir(tmp_path / "ce", sd_ce, words)
+    write_model_dir(tmp_path / "enc", sd_q, words, with_config=False)
+    n = 2500
+    V = synth.unit_rows(n, 384, 51)
+    n_rev, stars = synth.metadata(n, 52)
+    meta = pd.DataFrame({"sku": synth.skus(n), "n_reviews": n_rev, "avg_stars": stars, "last_ts": np.arange(n),
+                         "agg_text": synth.text_corpus(n, 53, mean_len=30)})
+    blob = artifacts.build_bm25_blob(meta)
+    artifacts.save_artifacts(tmp_path / "data", meta, V, blob)
+    out = tmp_path / "out.json"
+    query = "soft cotton shirt"
+    rc = main(["-q", query, "-k", "8", "--rerank_k", "30", "--data-dir", str(tmp_path / "data"), "--json-out", str(out),
+               "--emb-model-dir", str(tmp_path / "enc"), "--rerank-model-dir", str(tmp_path / "ce"), "--gate-penalty", "1.0"])
+    assert rc == 0 and "Top results:" in capsys.readouterr().out
+    got = json.loads(out.read_text())["results"]
+    qvec = OC.encode_oracle(sd_q, [tok.encode_pair(query, None, 512)], n_layers=12, normalize=True)[0]
+    qvec_gpu = QueryEncoder.from_pretrained_dir(tmp_path / "enc").encode([query], normalize_embeddings=True)[0]
+    assert np.abs(qvec - qvec_gpu).max() < EMB_TOL
+    rr = lambda pairs: OC.predict_oracle(sd_ce, [tok.encode_pair(a, b, 512) for a, b in pairs], 6)
+    from oracle.primitives import l2_normalize
+    want, _, _, cand = run_search_oracle(query=query, qvec=qvec_gpu, meta=meta, V=l2_normalize(V),
+                                         bm25=BM25OkapiOracle(blob["corpus"]), bm25_skus=blob["skus"], k=8, rerank_k=30,
+                                         w_dense=0.55, w_bm25=0.15, w_rerank=0.15, w_prior=0.10, w_best=0.05, prior_C=20.0,
+                                         gate_penalty=1.0, flavour="cli", rerank_fn=rr)
+    exp = {r["sku"]: r for r in cli_rows(cand)}                     # every pool row, by sku
+    span = float(np.ptp(rr([(query, t[:2000]) for t in cand["agg_text"].tolist()[:30]])))
+    tol = 0.15 * (2 * LOGIT_TOL / span) + 2e-4
+    assert len(got) == 8 and len(set(r["sku"] for r in got) & set(want["sku"])) >= 6
+    for g in got:
+        e = exp[g["sku"]]
+        assert abs(g["rerank"] - e["rerank"]) <= 2 * LOGIT_TOL / span + 1e-4
+        assert abs(g["score"] - e["score"]) <= tol
+        for key in ("dense", "bm25", "prior"):
+            assert abs(g[key] - e[key]) <= 1.01e-4
