@@ -95,6 +95,25 @@ __global__ __launch_bounds__(256) void ce_embed_ln(const int32_t* __restrict__ t
 
 // gelu(x) = x/2 (1 + erf(x / sqrt 2)), erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
 // rounding of the result): 1 - (a1 t + .. + a5 t^5) exp(-z^2), t = 1 / (1 + p z), z = |x| / sqrt 2; one v_rcp, one v_exp.
+// Two values at a time on the packed fp32 pipe (v_pk_mul / v_pk_fma / v_pk_add: two lanes' worth per instruction):
+// the same formula; gelu(x) = x/2 * (x >= 0 ? 2 - q : q) with q = poly(t) t exp(-z^2) = 1 - erf(|x| / sqrt 2).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t ce_gelu2(f32x2_t x) {
+    const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2_t z = ax * 0.70710678118654752f;
+    const f32x2_t d = __builtin_elementwise_fma(z, (f32x2_t){0.3275911f, 0.3275911f}, (f32x2_t){1.f, 1.f});
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2_t poly = __builtin_elementwise_fma(t, (f32x2_t){1.061405429f, 1.061405429f}, (f32x2_t){-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2_t){1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2_t){-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(poly, t, (f32x2_t){0.254829592f, 0.254829592f});
+    const f32x2_t a = (z * z) * -1.4426950408889634f;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const f32x2_t q = (poly * t) * e;
+    const f32x2_t two_q = (f32x2_t){2.f, 2.f} - q;
+    const f32x2_t r = {x[0] < 0.f ? q[0] : two_q[0], x[1] < 0.f ? q[1] : two_q[1]};
+    return (x * 0.5f) * r;
+}
 __device__ __forceinline__ float ce_gelu(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
@@ -229,7 +248,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
                     float v0 = acc[i][j][e] + bv, v1 = acc[i][j][e + 1] + bv;      // rows R(e), R(e) + 1, column r32
-                    if (EPI == CE_EPI_GELU) { v0 = ce_gelu(v0); v1 = ce_gelu(v1); }
+                    if (EPI == CE_EPI_GELU) { const f32x2_t gg = ce_gelu2((f32x2_t){v0, v1}); v0 = gg[0]; v1 = gg[1]; }
                     const float got = __shfl_xor(odd ? v0 : v1, 1, 64);
                     // even lane: row R(e), columns (c, c + 1);  odd lane: row R(e) + 1, columns (c - 1, c)
                     const bf16x2_t pk = odd ? bf16x2_t{(__bf16)got, (__bf16)v1} : bf16x2_t{(__bf16)v0, (__bf16)got};
@@ -442,10 +461,11 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         for (int g = 0; g < 4; ++g) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + ch * CE_FFN_CH + 8 * g + 4 * hh);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 4; r += 2) {
                 const int e = 4 * g + r;
-                const float v = ce_gelu(x0[e] + bv[r]);
-                xb[e >> 3][e & 7] = (__bf16)v;
+                const f32x2_t v = ce_gelu2((f32x2_t){x0[e] + bv[r], x0[e + 1] + bv[r + 1]});
+                xb[e >> 3][e & 7] = (__bf16)v[0];
+                xb[e >> 3][(e & 7) + 1] = (__bf16)v[1];
             }
         }
         // ---- out^T += W2c . X^T
