@@ -400,24 +400,37 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
 
-    // chunk staging: W1 rows j0 .. j0+31 (32 x 768 B = 1536 pieces of 16 B) and W2p columns j0 .. j0+31 of all 384 rows
-    // (384 x 64 B = 1536 pieces), 6 + 6 pieces per thread, moved in two halves (3 + 3 pieces) so that only 24 staging
-    // registers are live at a time: the rest of the budget goes to the fragment pipeline below
-    u32x4 p1[3], p2[3];
-    auto load_half = [&](int ch, int half) {
+    // chunk staging: a W1 chunk (rows j0 .. j0+31: 32 x 768 B) and a W2p chunk (columns j0 .. j0+31 of all 384 rows:
+    // 384 x 64 B) are 1536 pieces of 16 B each = 6 per thread; ONE set of six staging registers serves both in turn
+    u32x4 pw[6];
+    auto load_w1 = [&](int ch) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int id = tid + 256 * (3 * half + i);
-            p1[i] = *reinterpret_cast<const u32x4*>(W1 + (int64_t)(ch * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
-            p2[i] = *reinterpret_cast<const u32x4*>(W2p + (int64_t)(id >> 2) * CE_FFN + ch * CE_FFN_CH + (id & 3) * 8);
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 256 * i;
+            pw[i] = *reinterpret_cast<const u32x4*>(W1 + (int64_t)(ch * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
         }
     };
-    auto store_half = [&](unsigned short* buf, int half) {
+    auto load_w2 = [&](int ch) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int id = tid + 256 * (3 * half + i);
-            *reinterpret_cast<u32x4*>(buf + (id / 48) * CE_W1_LD + (id % 48) * 8) = p1[i];
-            *reinterpret_cast<u32x4*>(buf + CE_FFN_CH * CE_W1_LD + (id >> 2) * CE_W2_LD + (id & 3) * 8) = p2[i];
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 256 * i;
+            pw[i] = *reinterpret_cast<const u32x4*>(W2p + (int64_t)(id >> 2) * CE_FFN + ch * CE_FFN_CH + (id & 3) * 8);
+        }
+    };
+    auto w1_of = [&](int k) { return wbuf + (k & 1) * CE_FFN_BUF; };                          // LDS home of W1 chunk k
+    auto w2_of = [&](int k) { return wbuf + (k & 1) * CE_FFN_BUF + CE_FFN_CH * CE_W1_LD; };    // ... of W2 chunk k
+    auto store_w1 = [&](unsigned short* buf) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(buf + (id / 48) * CE_W1_LD + (id % 48) * 8) = pw[i];
+        }
+    };
+    auto store_w2 = [&](unsigned short* buf) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(buf + (id >> 2) * CE_W2_LD + (id & 3) * 8) = pw[i];
         }
     };
     auto lds_barrier = [&]() {
@@ -429,48 +442,69 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     constexpr int NCH = CE_FFN / CE_FFN_CH;          // 48 chunks
     constexpr int DEPTH = 4;                         // A fragments in flight ahead of their MFMA: one wave per SIMD, so the
                                                      // LDS latency (~100+ cycles against 32 per MFMA) is hidden by depth
-    load_half(0, 0); store_half(wbuf, 0);
-    load_half(0, 1); store_half(wbuf, 1);
-    load_half(1, 0);                                                       // first half of chunk 1: in flight over the barrier
+    // Software pipeline over the chunks: the first product of chunk ch + 1 (matrix pipe) runs while the GELU of chunk ch
+    // (vector pipe: one v_rcp + one v_exp per value, the longest VALU stretch of the kernel) is computed -- they are
+    // independent; only then does the second product of chunk ch consume the GELU's output.  With one wave per SIMD
+    // nothing else would fill the matrix pipe during the GELU.
+    load_w1(0); store_w1(w1_of(0));
+    load_w2(0); store_w2(w2_of(0));
+    load_w1(1); store_w1(w1_of(1));
     lds_barrier();
-    for (int ch = 0; ch < NCH; ++ch) {
-        const unsigned short* w1c = wbuf + (ch & 1) * CE_FFN_BUF;
-        const unsigned short* w2c = w1c + CE_FFN_CH * CE_W1_LD;
-        unsigned short* nxt = wbuf + ((ch + 1) & 1) * CE_FFN_BUF;
-        const bool more = ch + 1 < NCH;                                    // (its first half was requested a chunk ago)
-        // ---- X^T = W1c . h^T  (one accumulator chain: a 32x32 MFMA's issue interval covers its own latency)
-        f32x16 x0;
+    f32x16 xc;                                       // raw X^T of the current chunk (before bias / GELU)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) x0[e] = 0.f;
-        {
-            const unsigned short* ap = w1c + c * CE_W1_LD + 8 * hh;
+    for (int e = 0; e < 16; ++e) xc[e] = 0.f;
+    {
+        const unsigned short* ap = w1_of(0) + c * CE_W1_LD + 8 * hh;
+        bf16x8 af[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + 16 * i);
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            xc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], xc, 0, 0, 0);
+            if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    lds_barrier();                                                         // every wave is done with W1 chunk 0: its home is reused below
+    load_w1(2);                                                            // stored by iteration 0
+    for (int ch = 0; ch < NCH; ++ch) {
+        const bool more = ch + 1 < NCH;
+        // register e of lane half hh is feature (e & 3) + 8 (e >> 2) + 4 hh of the chunk
+        f32x4 bv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(b1 + ch * CE_FFN_CH + 8 * g + 4 * hh);
+        bf16x8 xb[2];
+        auto gelu_pair = [&](int k) {                                      // values 2k, 2k + 1 of xc -> xb
+            const int e = 2 * k;
+            const f32x2_t v = ce_gelu2((f32x2_t){xc[e] + bv[e >> 2][e & 3], xc[e + 1] + bv[e >> 2][(e & 3) + 1]});
+            xb[e >> 3][e & 7] = (__bf16)v[0];
+            xb[e >> 3][(e & 7) + 1] = (__bf16)v[1];
+        };
+        f32x16 xn;                                                         // X^T of chunk ch + 1
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xn[e] = 0.f;
+        if (more) {
+            // ---- X^T(ch + 1) = W1 chunk . h^T on the matrix pipe, GELU(ch) on the vector pipe, interleaved
+            const unsigned short* ap = w1_of(ch + 1) + c * CE_W1_LD + 8 * hh;
             bf16x8 af[DEPTH];
 #pragma unroll
             for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + 16 * i);
 #pragma unroll
             for (int s = 0; s < 24; ++s) {
-                x0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], x0, 0, 0, 0);
+                xn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], xn, 0, 0, 0);
                 if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
+                if (s % 3 == 0) gelu_pair(s / 3);                           // 8 pairs over the 24 MFMA slots
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        if (more) { store_half(nxt, 0); load_half(ch + 1, 1); }            // second half under the GELU and the second product
-        // ---- + b1, GELU, -> bf16: register e of lane half hh is feature (e & 3) + 8 (e >> 2) + 4 hh of the chunk
-        bf16x8 xb[2];
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + ch * CE_FFN_CH + 8 * g + 4 * hh);
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const int e = 4 * g + r;
-                const f32x2_t v = ce_gelu2((f32x2_t){x0[e] + bv[r], x0[e + 1] + bv[r + 1]});
-                xb[e >> 3][e & 7] = (__bf16)v[0];
-                xb[e >> 3][(e & 7) + 1] = (__bf16)v[1];
-            }
+            for (int k = 0; k < 8; ++k) gelu_pair(k);
         }
-        // ---- out^T += W2c . X^T
+        if (ch + 2 < NCH) store_w1(w1_of(ch + 2));                         // (its home held W1 chunk ch, last read a barrier ago)
+        if (more) load_w2(ch + 1);
+        // ---- out^T += W2 chunk . X^T(ch)
         {
-            const unsigned short* ap = w2c + c * CE_W2_LD + 8 * hh;
+            const unsigned short* ap = w2_of(ch) + c * CE_W2_LD + 8 * hh;
             auto frag = [&](int i) { return *reinterpret_cast<const bf16x8*>(ap + (i >> 1) * 32 * CE_W2_LD + 16 * (i & 1)); };
             bf16x8 af[DEPTH];
 #pragma unroll
@@ -482,9 +516,10 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (more) store_half(nxt, 1);
-        if (ch + 2 < NCH) load_half(ch + 2, 0);                            // in flight over the barrier and the next first product
+        if (more) store_w2(w2_of(ch + 1));                                 // (its home held W2 chunk ch - 1)
+        if (ch + 3 < NCH) load_w1(ch + 3);                                 // in flight over the barrier; stored next iteration
         lds_barrier();
+        xc = xn;
     }
 
     // ---- + b2 + residual, LayerNorm over the token's 384 features (this lane: 192 of them, lane ^ 32 the others)
