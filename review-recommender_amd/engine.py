@@ -349,13 +349,12 @@ class SearchEngine:
             return None   # model missing -> zeros (app/app_product_search.py:275)
 
         def fn(rows: np.ndarray) -> np.ndarray:
-            out = np.zeros(rows.shape, dtype=np.float32)
-            for b in range(rows.shape[0]):
-                texts = self._texts.iloc[rows[b]].str.slice(0, 2000).tolist()
-                pairs = [(query, t) for t in texts]
-                out[b] = np.array(self.cross_encoder.predict(pairs, batch_size=64,
-                                                             show_progress_bar=False), dtype=np.float32)
-            return out
+            # every (query, text[:2000]) pair of the batch in ONE predict call: the packed forward has no use for
+            # per-query mini-batches (app/app_product_search.py:272-278 builds the pairs the same way, per query)
+            texts = self._texts.iloc[rows.reshape(-1)].str.slice(0, 2000).tolist()
+            pairs = [(query, t) for t in texts]
+            scores = np.asarray(self.cross_encoder.predict(pairs, batch_size=64, show_progress_bar=False), dtype=np.float32)
+            return scores.reshape(rows.shape)
         return fn
 
     # ------------------------------------------------------------------ API
