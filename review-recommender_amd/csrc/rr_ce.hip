@@ -375,6 +375,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
 #define CE_W2_LD (CE_FFN_CH + 8)    // LDS row of a W2 chunk: 32 bf16 + 16 B pad
 #define CE_FFN_BUF (CE_FFN_CH * CE_W1_LD + CE_H * CE_W2_LD)     // bf16 elements per chunk buffer
 
+// DEPTH: A fragments in flight.  STAGGER rotates the chunk order per workgroup (it spreads the L2 lines the CUs ask for at
+// one time, but makes a token's rounding depend on where it sits in the batch): measured r02 at 256 x 512 tokens, whole
+// forward: <4, false> 6.26 ms, <8, false> 6.38 ms, <4, true> 6.38 ms -- neither LDS depth nor L2 hot-spotting is what
+// bounds the kernel (a single wave per SIMD issues its VALU, LDS and MFMA work in order); only <4, false> is built.
+template <int DEPTH, bool STAGGER>
 __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     unsigned short* __restrict__ hb, float* __restrict__ h32, int M,
     const unsigned short* __restrict__ W1, const float* __restrict__ b1,       // [1536][384], [1536]
@@ -440,15 +445,17 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     };
 
     constexpr int NCH = CE_FFN / CE_FFN_CH;          // 48 chunks
-    constexpr int DEPTH = 4;                         // A fragments in flight ahead of their MFMA: one wave per SIMD, so the
-                                                     // LDS latency (~100+ cycles against 32 per MFMA) is hidden by depth
+    // DEPTH A fragments are in flight ahead of their MFMA: one wave per SIMD, so the LDS latency (~100+ cycles against
+    // 32 per MFMA) is hidden by depth
+    const int rot = STAGGER ? (int)((blockIdx.x * 7u) % NCH) : 0;          // (experiment: spreads the L2 lines the CUs ask for)
+    auto chunk_of = [&](int k) { return STAGGER ? (k + rot) % NCH : k; };
     // Software pipeline over the chunks: the first product of chunk ch + 1 (matrix pipe) runs while the GELU of chunk ch
     // (vector pipe: one v_rcp + one v_exp per value, the longest VALU stretch of the kernel) is computed -- they are
     // independent; only then does the second product of chunk ch consume the GELU's output.  With one wave per SIMD
     // nothing else would fill the matrix pipe during the GELU.
-    load_w1(0); store_w1(w1_of(0));
-    load_w2(0); store_w2(w2_of(0));
-    load_w1(1); store_w1(w1_of(1));
+    load_w1(chunk_of(0)); store_w1(w1_of(0));
+    load_w2(chunk_of(0)); store_w2(w2_of(0));
+    load_w1(chunk_of(1)); store_w1(w1_of(1));
     lds_barrier();
     f32x16 xc;                                       // raw X^T of the current chunk (before bias / GELU)
 #pragma unroll
@@ -466,13 +473,13 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         }
     }
     lds_barrier();                                                         // every wave is done with W1 chunk 0: its home is reused below
-    load_w1(2);                                                            // stored by iteration 0
+    load_w1(chunk_of(2));                                                  // stored by iteration 0
     for (int ch = 0; ch < NCH; ++ch) {
         const bool more = ch + 1 < NCH;
         // register e of lane half hh is feature (e & 3) + 8 (e >> 2) + 4 hh of the chunk
         f32x4 bv[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(b1 + ch * CE_FFN_CH + 8 * g + 4 * hh);
+        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(b1 + chunk_of(ch) * CE_FFN_CH + 8 * g + 4 * hh);
         bf16x8 xb[2];
         auto gelu_pair = [&](int k) {                                      // values 2k, 2k + 1 of xc -> xb
             const int e = 2 * k;
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
             for (int k = 0; k < 8; ++k) gelu_pair(k);
         }
         if (ch + 2 < NCH) store_w1(w1_of(ch + 2));                         // (its home held W1 chunk ch, last read a barrier ago)
-        if (more) load_w2(ch + 1);
+        if (more) load_w2(chunk_of(ch + 1));
         // ---- out^T += W2 chunk . X^T(ch)
         {
             const unsigned short* ap = w2_of(ch) + c * CE_W2_LD + 8 * hh;
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
             }
         }
         if (more) store_w2(w2_of(ch + 1));                                 // (its home held W2 chunk ch - 1)
-        if (ch + 3 < NCH) load_w1(ch + 3);                                 // in flight over the barrier; stored next iteration
+        if (ch + 3 < NCH) load_w1(chunk_of(ch + 3));                                 // in flight over the barrier; stored next iteration
         lds_barrier();
         xc = xn;
     }
@@ -949,7 +956,7 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
         hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP);
         hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
         hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512));
-        hipFuncSetAttribute((const void*)ce_ffn_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CE_FFN_BUF * 2);
+        hipFuncSetAttribute((const void*)ce_ffn_fused<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CE_FFN_BUF * 2);
         attr_set = true;
     }
     const int smax_pad = (max_len + 31) & ~31;
@@ -981,8 +988,9 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
         hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rctx, L.wo, L.bo, Mr, CE_H,
                            CE_H, rb, r32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
         if (!unfused) {
-            hipLaunchKernelGGL(ce_ffn_fused, dim3((unsigned)((Mr + CE_FFN_TOK - 1) / CE_FFN_TOK)), dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1,
-                               L.w2p, L.b2, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
+            const dim3 fg((unsigned)((Mr + CE_FFN_TOK - 1) / CE_FFN_TOK));
+            hipLaunchKernelGGL((ce_ffn_fused<4, false>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
+                               L.ln2_b, ce->cfg.ln_eps);
         } else {
             hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(Mr, 128, CE_FFN / 384)), dim3(512), ldsP, st, rb, L.w1, L.b1, Mr,
                                CE_FFN, CE_H, rint, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
