@@ -208,11 +208,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the search path has no CPU fallback")
+    # rehearsal switch (never set by the driver): RR_BENCH_REHEARSE=gloo runs the N > 1 code path with every rank on
+    # cuda:0 and the gloo backend (RCCL refuses two ranks on one device), to exercise sharding, the setup collectives,
+    # the payload exchange and the merge on a one-GPU box.  Timings of such a run mean nothing.
+    rehearse = os.environ.get("RR_BENCH_REHEARSE", "")
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group(rehearse)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from review_recommender_amd.device_corpus import build_device_shard
     from review_recommender_amd.engine import FusionWeights

@@ -120,8 +120,14 @@ def build_device_shard(torch, dist, *, docs: int, rank: int, world: int, dev, vo
         df = df_local.clone()
         tot_len = dl.long().sum().reshape(1)
         if world > 1:
-            dist.all_reduce(df)
-            dist.all_reduce(tot_len)
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(df)
+                dist.all_reduce(tot_len)
+            else:                                   # gloo rehearsal: reduce on the host
+                df_h, tl_h = df.cpu(), tot_len.cpu()
+                dist.all_reduce(df_h)
+                dist.all_reduce(tl_h)
+                df, tot_len = df_h.to(dev), tl_h.to(dev)
         avgdl = int(tot_len.item()) / docs
         idf = torch.from_numpy(idf_with_floor(df.cpu().numpy(), docs)).to(dev)
         h = C.c_void_p()

@@ -84,6 +84,10 @@ def exchange(buf, world: int, group=None):
         return out
     if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(out, buf, group=group)       # RCCL over xGMI
+    elif buf.is_cuda:                                             # gloo rehearsal on a GPU box: gloo gathers host tensors
+        host = torch.empty((world, buf.numel()), dtype=torch.uint8)
+        dist.all_gather([host[r] for r in range(world)], buf.cpu(), group=group)
+        out.copy_(host)
     else:                                                         # gloo (CPU tests)
         parts = [out[r] for r in range(world)]
         dist.all_gather(parts, buf, group=group)
@@ -110,6 +114,10 @@ def exchange_scores(local, n_pairs: int, world: int, group=None):
     out = torch.empty(world * share, dtype=torch.float32, device=local.device)
     if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(out, buf, group=group)
+    elif buf.is_cuda:                                             # gloo rehearsal on a GPU box
+        host = torch.empty(world * share, dtype=torch.float32)
+        dist.all_gather([host[r * share:(r + 1) * share] for r in range(world)], buf.cpu(), group=group)
+        out.copy_(host)
     else:
         dist.all_gather([out[r * share:(r + 1) * share] for r in range(world)], buf, group=group)
     parts = []
