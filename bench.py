@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="matrix storage (bf16: BASELINE configs[3]; queries and arithmetic stay fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rerank-k", type=int, default=0,
+                    help="BASELINE config 5: cross-encoder rerank of the first RERANK_K pool rows per query (K5, seeded random "
+                         "weights of the ms-marco-MiniLM-L-6 shape, synthetic product token ids built on the device); "
+                         "use with --batch 64 --k 20")
     ap.add_argument("--force-payload", action="store_true",
                     help="diagnostic: with one rank, still pack / exchange / merge the shard payload")
     return ap.parse_args()
@@ -197,6 +201,51 @@ def _csr_oracle(torch, a, n_docs, vocab):
                          a["avgdl"])
 
 
+class SyntheticPairScorer:
+    """The rerank step of BASELINE config 5 with synthetic text: `rerank_fn(query_idx, rows) -> scores` for
+    ShardedSearcher.search_batch_dev.  Every product row has a deterministic pseudo-random token sequence of 54..501 ids
+    (the reference cuts texts at 2000 characters, ~400-500 WordPiece tokens), every query 8; the packed
+    [CLS] q [SEP] text [SEP] sequences are built with torch ops on the device and scored by csrc/rr_ce.hip
+    (seeded random weights: real ms-marco weights are not available offline).  The pool rows arrive on the host and the
+    scores go back through it, as in the reference's flow (texts are host data)."""
+
+    def __init__(self, torch, dev, seed=7, chunk_tokens=1 << 20):
+        from review_recommender_amd import synth
+        from review_recommender_amd.cross_encoder import CrossEncoder
+        self.torch, self.dev, self.chunk = torch, dev, chunk_tokens
+        self.ce = CrossEncoder(synth.bert_state_dict(seed, n_layers=6, n_labels=1), device=dev.index)
+        self.pairs = 0
+        self.tokens = 0
+        self.ms = 0.0
+
+    def __call__(self, qi, rows):
+        torch = self.torch
+        n = len(rows)
+        out = torch.empty(n, dtype=torch.float32, device=self.dev)
+        r = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64)).to(self.dev)
+        qq = torch.from_numpy(np.ascontiguousarray(qi, dtype=np.int64)).to(self.dev)
+        ltxt = 54 + (r * 2654435761 % 448)                         # text tokens per product
+        length = ltxt + 11                                         # [CLS] 8 query tokens [SEP] text [SEP]
+        per = max(1, self.chunk // 512)
+        for s0 in range(0, n, per):
+            ln = length[s0:s0 + per]
+            m = ln.numel()
+            pos = torch.arange(512, device=self.dev).expand(m, 512)
+            mask = pos < ln[:, None]
+            hq = (qq[s0:s0 + per, None] * 40503 + pos * 9973) % 29000 + 1000
+            ht = (r[s0:s0 + per, None] * 7919 + pos * 104729) % 29000 + 1000
+            tok = torch.where(pos == 0, 101, torch.where(pos <= 8, hq, torch.where((pos == 9) | (pos == ln[:, None] - 1), 102, ht)))
+            typ = (pos > 9).int()
+            cu = torch.zeros(m + 1, dtype=torch.int32, device=self.dev)
+            cu[1:] = torch.cumsum(ln, 0).int()
+            logits = self.ce.model.forward_packed_dev(tok[mask].int().contiguous(), typ[mask].contiguous(),
+                                                      pos[mask].int().contiguous(), cu, m, 512, 0)
+            out[s0:s0 + m] = logits[:, 0]
+            self.tokens += int(cu[-1].item())
+        self.pairs += n
+        return out.cpu().numpy()
+
+
 def main():
     args = parse()
     import torch
@@ -238,11 +287,19 @@ def main():
     pin_order = torch.empty((args.batch, args.k), dtype=torch.int32).pin_memory()
     pin_final = torch.empty((args.batch, pool), dtype=torch.float64).pin_memory()
 
+    rerank_fn = None
+    if args.rerank_k > 0:
+        rerank_fn = SyntheticPairScorer(torch, dev, seed=7)
+        w = FusionWeights(w_dense=0.4, w_bm25=0.2, w_rerank=0.3, w_prior=0.1, w_best=0.0, gate_penalty=1.0)
+        pool = max(args.k, args.rerank_k, 150)
+        pin_rows = torch.empty((args.batch, pool), dtype=torch.int64).pin_memory()
+        pin_final = torch.empty((args.batch, pool), dtype=torch.float64).pin_memory()
+
     def step(i):
         q_pin, terms = qsets[i % len(qsets)]
         q = q_dev[i % 2]
         q.copy_(q_pin, non_blocking=True)                        # H2D: query vectors (token ids: inside search)
-        rows, cols, order = sharded.search_batch_dev(q, terms, args.k, w)
+        rows, cols, order = sharded.search_batch_dev(q, terms, args.k, w, rerank_k=args.rerank_k, rerank_fn=rerank_fn)
         pin_rows.copy_(rows, non_blocking=True)                  # D2H: the answer
         pin_order.copy_(order, non_blocking=True)
         pin_final.copy_(cols[:, 7, :], non_blocking=True)
@@ -353,7 +410,13 @@ def main():
             # the single-query scan on the same shard: the HBM-bound end of the same path
             "roofline_single_query": single,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if rerank_fn is not None:
+            out["metric"] = f"queries/sec, hybrid + cross-encoder rerank top-{args.rerank_k} -> top-{args.k}"
+            out["config"]["workload"] += (f"; rerank of the first {args.rerank_k} pool rows per query by the K5 cross-encoder "
+                                          "(MiniLM-L6 shape, seeded weights, synthetic token ids 65..512 per pair)")
+            out["rerank"] = {"pairs_per_step": args.batch * args.rerank_k,
+                             "mean_tokens_per_pair": round(rerank_fn.tokens / max(rerank_fn.pairs, 1), 1)}
+        if world == 1 and not args.no_cpu_baseline and rerank_fn is None:
             out["cpu_baseline"] = cpu_baseline(torch, args, shard, qsets)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -156,6 +156,20 @@ class BertEncoderGPU:
             start = end
         return out
 
+    def forward_packed_dev(self, tok, typ, pos, cu, n_seqs: int, max_len: int, mode: int = OUT_LOGITS):
+        """Forward over sequences that are already packed ON THE DEVICE (int32 torch tensors: token ids, type ids,
+        position ids per token; cu_seqlens per sequence): returns a device tensor, no host hop.  Asynchronous on
+        torch's current stream.  Used where the pairs are assembled on the GPU (bench.py's rerank mode)."""
+        torch = self._torch
+        n_tokens = int(tok.numel())
+        width = {OUT_LOGITS: self.n_labels, OUT_CLS: HIDDEN, OUT_HIDDEN: HIDDEN}[mode]
+        out = torch.empty((n_tokens if mode == OUT_HIDDEN else n_seqs, width), dtype=torch.float32, device=self._dev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(_lib.load().rr_ce_forward_dev(
+            self._h, p(tok), p(typ), p(pos), p(cu), int(n_seqs), n_tokens, int(max_len), mode, p(out),
+            C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)), "rr_ce_forward_dev")
+        return out
+
     def last_forward_ms(self) -> float:
         ms = C.c_float()
         _lib.check(_lib.load().rr_ce_last_forward_ms(self._h, C.byref(ms)), "rr_ce_last_forward_ms")
