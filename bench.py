@@ -334,6 +334,14 @@ def main():
     dt = float(t.item())
     total_ms, launches = _scan_stats(index)
     info = _scan_info(index)
+    # the answer of the last step, as it sits in the pinned buffers: cheap invariants (parity itself is the tests' job:
+    # tests/test_gpu_bench_config.py checks this very configuration against the oracle)
+    r_h, o_h, f_h = pin_rows.numpy(), pin_order.numpy().astype(np.int64), pin_final.numpy()
+    top = np.take_along_axis(f_h, o_h, axis=1)
+    ok = (r_h.min() >= 0 and r_h.max() < args.docs and np.all(np.diff(top, axis=1) <= 0)
+          and all(len(set(o.tolist())) == o_h.shape[1] for o in o_h[:8]) and np.isfinite(top).all())
+    if not ok:
+        raise SystemExit("bench.py: the last step's answer violates its invariants (rows in range, top-k sorted, distinct)")
     per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
     if os.environ.get("RR_BENCH_DEBUG"):
         print("per-step ms:", np.round(per_step, 3).tolist(), file=sys.stderr, flush=True)
