@@ -575,143 +575,6 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     }
 }
 
-// ------------------------------------------------------------------ projections in the same transposed form
-// out^T[n][tok] = W[n] . a[tok] with the wave's 32 tokens persistent on the MFMA columns (their bf16 rows in 96
-// registers, loaded once) and W streamed through LDS in 32-row chunks, 12 chunks (384 outputs) per pass:
-//   NPASS = 3, CE_EPI_BIAS     QKV: three passes, each ends by adding the bias and storing 4 consecutive outputs
-//                              (8 bytes) per lane and register group
-//   NPASS = 1, CE_EPI_RES_LN   attention output: + bias + residual, LayerNorm over the lane pair, fp32 + bf16
-// Against the tiled ce_gemm: the A operand is read from HBM exactly once and never re-staged through LDS, one
-// ds_read_b128 per MFMA (read four ahead), one barrier per 24 MFMAs, no cross-wave LayerNorm reduction.
-template <int NPASS, int EPI>
-__global__ __launch_bounds__(256, 1) void ce_proj_t(
-    const unsigned short* __restrict__ A, int M, const unsigned short* __restrict__ W, const float* __restrict__ bias,
-    unsigned short* __restrict__ outb, int N, float* __restrict__ res32, const float* __restrict__ ln_g,
-    const float* __restrict__ ln_b, float ln_eps) {
-    static_assert(EPI != CE_EPI_RES_LN || NPASS == 1, "LayerNorm needs the whole row in one pass");
-    extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
-    unsigned short* wbuf = reinterpret_cast<unsigned short*>(ce_smem);          // [2][32][CE_W1_LD]
-    constexpr int CHB = CE_FFN_CH * CE_W1_LD;
-    constexpr int DEPTH = 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, hh = lane >> 5;
-    int64_t tok = (int64_t)blockIdx.x * CE_FFN_TOK + wave * 32 + c;
-    const bool live = tok < M;
-    tok = live ? tok : M - 1;
-    bf16x8 hf[24];
-#pragma unroll
-    for (int s = 0; s < 24; ++s) hf[s] = *reinterpret_cast<const bf16x8*>(A + tok * CE_H + 16 * s + 8 * hh);
-
-    u32x4 pw[6];
-    auto load_w = [&](int k) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 256 * i;
-            pw[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)(k * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
-        }
-    };
-    auto store_w = [&](unsigned short* buf) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 256 * i;
-            *reinterpret_cast<u32x4*>(buf + (id / 48) * CE_W1_LD + (id % 48) * 8) = pw[i];
-        }
-    };
-    auto lds_barrier = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    constexpr int TOTAL = NPASS * 12;
-    load_w(0); store_w(wbuf);
-    if (TOTAL > 1) load_w(1);
-    lds_barrier();
-#pragma unroll 1
-    for (int p = 0; p < NPASS; ++p) {
-        f32x16 acc[12];
-#pragma unroll
-        for (int nb = 0; nb < 12; ++nb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < 12; ++nb) {
-            const int k = p * 12 + nb;
-            const unsigned short* ap = wbuf + (k & 1) * CHB + c * CE_W1_LD + 8 * hh;
-            bf16x8 af[DEPTH];
-#pragma unroll
-            for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + 16 * i);
-#pragma unroll
-            for (int s = 0; s < 24; ++s) {
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], acc[nb], 0, 0, 0);
-                if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (k + 1 < TOTAL) store_w(wbuf + ((k + 1) & 1) * CHB);          // (its home held chunk k - 1, last read a barrier ago)
-            if (k + 2 < TOTAL) load_w(k + 2);
-            lds_barrier();
-        }
-        if constexpr (EPI == CE_EPI_BIAS) {
-            if (live) {
-#pragma unroll
-                for (int nb = 0; nb < 12; ++nb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = p * CE_H + nb * 32 + 8 * g + 4 * hh;
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
-                        bf16x4 yb;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) yb[r] = (__bf16)(acc[nb][4 * g + r] + bv[r]);
-                        *reinterpret_cast<bf16x4*>(outb + tok * N + n) = yb;
-                    }
-            }
-        } else {
-            float sum = 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 12; ++nb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = nb * 32 + 8 * g + 4 * hh;
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(res32 + tok * CE_H + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = (acc[nb][4 * g + r] + bv[r]) + rv[r];
-                        acc[nb][4 * g + r] = v;
-                        sum += v;
-                    }
-                }
-            sum += __shfl_xor(sum, 32, 64);
-            const float mean = sum * (1.f / CE_H);
-            float var = 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 12; ++nb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) { const float d = acc[nb][e] - mean; var += d * d; }
-            var += __shfl_xor(var, 32, 64);
-            const float rstd = rsqrtf(var * (1.f / CE_H) + ln_eps);
-            if (live) {
-#pragma unroll
-                for (int nb = 0; nb < 12; ++nb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = nb * 32 + 8 * g + 4 * hh;
-                        const f32x4 gv = *reinterpret_cast<const f32x4*>(ln_g + n);
-                        const f32x4 be = *reinterpret_cast<const f32x4*>(ln_b + n);
-                        f32x4 y;
-                        bf16x4 yb;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            y[r] = (acc[nb][4 * g + r] - mean) * rstd * gv[r] + be[r];
-                            yb[r] = (__bf16)y[r];
-                        }
-                        *reinterpret_cast<f32x4*>(res32 + tok * CE_H + n) = y;
-                        *reinterpret_cast<bf16x4*>(outb + tok * CE_H + n) = yb;
-                    }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------ attention: one workgroup per (sequence, head)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define CE_KS_LD 40         // K rows in LDS: 32 bf16 + 8 pad = 80 B (conflict-free ds_read_b128 over 16 rows)
@@ -1104,7 +967,6 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     const size_t ldsB = (size_t)(128 + 384) * CE_LDK * 2;
     const size_t ldsP = 8 * 64 * (96 + 8) * 2;          // plain epilogues stage eight 64 x 96 sub-tiles (> the K-tile buffers)
     const size_t ldsF = (size_t)2 * CE_FFN_BUF * 2;     // fused FFN: two chunk buffers
-    const size_t ldsT = (size_t)2 * CE_FFN_CH * CE_W1_LD * 2;   // transposed projections: two W chunk buffers
     static const bool unfused = getenv("RR_CE_UNFUSED") != nullptr;   // A/B: FFN as two GEMM launches
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
@@ -1117,22 +979,17 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
         unsigned short* rb = cls_tail ? ce->hbc : ce->hb;
         unsigned short* rctx = cls_tail ? ce->ctxc : ce->ctx;
         unsigned short* rint = cls_tail ? ce->interc : ce->inter;
-        if (!unfused)
-            hipLaunchKernelGGL((ce_proj_t<3, CE_EPI_BIAS>), dim3((unsigned)((T + CE_FFN_TOK - 1) / CE_FFN_TOK)), dim3(256), ldsT, st, ce->hb, T,
-                               L.wqkv, L.bqkv, ce->qkv, 3 * CE_H, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
-        else
-            hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 384)), dim3(512), ldsP, st, ce->hb, L.wqkv,
-                               L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
+        // (the transposed, token-persistent form of the fused FFN was also built for these two projections and measured
+        //  slower than the tiled GEMM: QKV 262 vs 222 us, attention output 154 vs 124 us per layer at 131 072 tokens -- with
+        //  nothing to fuse, one wave per SIMD loses to eight waves per tile)
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 384)), dim3(512), ldsP, st, ce->hb, L.wqkv,
+                           L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
         hipLaunchKernelGGL(ce_attention, dim3((unsigned)n_seqs, CE_HEADS), dim3(CE_ATT_THREADS), ce_attention_lds(smax_pad), st,
                            ce->qkv, d_cu_seqlens, ce->ctx, 0.17677669529663687f /* 1 / sqrt(32) */, smax_pad,
                            cls_tail ? ce->ctxc : (unsigned short*)nullptr);
         if (cls_tail) hipLaunchKernelGGL(ce_gather_cls, dim3((unsigned)n_seqs), dim3(128), 0, st, ce->h32, d_cu_seqlens, ce->h32c);
-        if (!unfused)
-            hipLaunchKernelGGL((ce_proj_t<1, CE_EPI_RES_LN>), dim3((unsigned)((Mr + CE_FFN_TOK - 1) / CE_FFN_TOK)), dim3(256), ldsT, st, rctx, Mr,
-                               L.wo, L.bo, rb, CE_H, r32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
-        else
-            hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rctx, L.wo, L.bo, Mr, CE_H,
-                               CE_H, rb, r32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
+        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rctx, L.wo, L.bo, Mr, CE_H,
+                           CE_H, rb, r32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
         if (!unfused) {
             const dim3 fg((unsigned)((Mr + CE_FFN_TOK - 1) / CE_FFN_TOK));
             hipLaunchKernelGGL((ce_ffn_fused<4, false>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
