@@ -62,8 +62,8 @@ extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim
         e = hipEventCreate(&ix->ring0[i]);
         if (e == hipSuccess) e = hipEventCreate(&ix->ring1[i]);
     }
-    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sel_trace, sizeof(int32_t) * 16 * RR_FLT_MAXQ);
-    if (e == hipSuccess) e = hipMalloc(&ix->d_qplanes, (size_t)3 * 64 * 384 * 2);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sel_trace, sizeof(int32_t) * 16 * RR_SEL_MAXQ);
+    if (e == hipSuccess) e = hipMalloc(&ix->d_qplanes, (size_t)2 * 3 * 64 * 384 * 2)   /* two sets of query planes (paired filter-scan launches) */;
     if (e == hipSuccess) e = hipMalloc(&ix->d_x3, rr_x3_scratch_bytes());
     if (e == hipSuccess) e = hipMalloc(&ix->d_q, sizeof(float) * (size_t)RR_MAX_BATCH * ix->dim_pad);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_rows_out, sizeof(int64_t) * (size_t)RR_MAX_BATCH * RR_MAX_POOL);

@@ -6,6 +6,7 @@
 #define RR_MAX_SCAN_WAVES 8192   // 2048 workgroups x 4 waves: upper bound of any resident grid
 #define RR_MFMA_MAXQ 64          // queries per exact matrix-core scan launch
 #define RR_FLT_MAXQ 128          // queries per filter-scan launch (rr_dense_flt.hip)
+#define RR_SEL_MAXQ 256          // queries one selection / rescoring launch may cover: two filter-scan launches (sets)
 #define RR_FLT_SAMP_CAP 8192      // sampled tiles of the store prefilter (rr_flt_sample)
 #define RR_FLT_NO_BOUND 1000     // rr_dense_chunk_flt: no finite row-norm bound, use the exact scans
 #define RR_FLT_SMALL 1001        // rr_dense_chunk_flt: too few tiles for the filter, use the VALU scans
@@ -52,6 +53,7 @@ void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int
 // Two-pass selection of the split-operand scan (see rr_select_mtiles in rr_dense.hip).
 #define RR_X3_MCAP 16384         // M-tiles (8 or 16 rows) one query may ask to have rescored
 struct rr_x3_scratch {           // (every array RR_FLT_MAXQ queries long)
+    // (every array RR_SEL_MAXQ queries long: a selection launch may follow two scan launches)
     uint32_t* mtiles;            // [q][RR_X3_MCAP] M-tile ids to rescore
     int32_t* count;              // [q] how many
     uint32_t* tau;               // [q] key threshold of the query's rows
@@ -63,8 +65,12 @@ rr_x3_scratch rr_x3_scratch_of(const rr_index* ix);
 size_t rr_x3_scratch_bytes();
 // `eps` (device, per query, may be null): the scan's scores are approximations within eps of the scores
 // the rescoring will produce; M-tiles are then opened down to tau - 2 eps and rows kept down to tau - eps.
+// `nq_b` > 0: the launch covers TWO scan launches (sets) of the same geometry: queries [0, nq) come from set 0, [nq,
+// nq + nq_b) from set 1, whose tile / group maxima sit `set_stride_words` 4-byte words behind set 0's and whose eps /
+// sigma entries start at index RR_FLT_MAXQ.
 void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st,
-                             const float* eps = nullptr, const float* sigma = nullptr);
+                             const float* eps = nullptr, const float* sigma = nullptr, int nq_b = 0,
+                             int64_t mmax_set_stride = 0, int64_t smax_set_stride = 0);
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st);
 // Waves a kernel can keep resident on the device (occupancy x CUs x waves per workgroup).

@@ -769,12 +769,23 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
     rr_scan_geom G, const float* __restrict__ mmax, const uint32_t* __restrict__ smax, int pool,
     uint32_t* __restrict__ out_mtiles, int32_t* __restrict__ out_count, uint32_t* __restrict__ out_tau,
     int32_t* __restrict__ fb, int32_t* __restrict__ dbg, const float* __restrict__ eps,
-    const float* __restrict__ sigma) {
+    const float* __restrict__ sigma, int nq_a, int nq_b, int64_t mmax_set_stride, int64_t smax_set_stride) {
     __shared__ uint32_t cnt[2][3][16];
     __shared__ uint32_t counters[4];
     __shared__ uint32_t list2[RR_SEL_LCAP];
     const int tid = threadIdx.x;
-    const int q = blockIdx.x;
+    // Query Q of the launch belongs to scan launch (set) 0 or 1; inside its set it is slot q.  Per-query OUTPUT arrays
+    // (mtiles, count, tau, fb, dbg) are indexed by Q; the set's maxima by slot q; eps / sigma by set * RR_FLT_MAXQ + q.
+    const int Q = blockIdx.x;
+    const int set = (nq_b > 0 && Q >= nq_a) ? 1 : 0;
+    const int q = set ? Q - nq_a : Q;
+    const int nq_set = set ? nq_b : nq_a;
+    mmax += set * mmax_set_stride;
+    smax += set * smax_set_stride;
+    if (eps) eps += set * RR_FLT_MAXQ;
+    if (sigma) sigma += set * RR_FLT_MAXQ;
+    out_mtiles += (int64_t)(Q - q) * RR_X3_MCAP;
+    out_count += Q - q; out_tau += Q - q; fb += Q - q; dbg += (Q - q) * 16;
     const int QS = G.qs;
     auto group_key_at = [&](int i) -> uint32_t { return smax[(int64_t)i * QS + q]; };
     const int gpw = G.gpw > 1 ? G.gpw : 1;
@@ -810,7 +821,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
             // 4-bit gap codes; upper bound of M-tile g = max - steps(code_g) * step.  Four 64-row tiles per thread and pass, all
             // loads issued before the first is looked at (the loop is otherwise one HBM round trip per pass).
             constexpr int U = 4;
-            const float step = rr_flt_gap_step(eps, gridDim.x);
+            const float step = rr_flt_gap_step(eps, nq_set);     // the resolution the set's scan launch encoded its gaps with
             const float openf = open <= 0x007FFFFFu ? -INFINITY : rr_key2f(open);   // (keys below key(-inf) are not scores)
             // store prefilter of the scan: tiles whose maximum stayed below sigma[q] may not have been stored.  They
             // cannot hold a candidate iff sigma[q] <= open; otherwise this query takes the exact fallback.  (Words of
@@ -955,23 +966,24 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
 rr_x3_scratch rr_x3_scratch_of(const rr_index* ix) {
     rr_x3_scratch s;
     char* p = static_cast<char*>(ix->d_x3);
-    s.mtiles = reinterpret_cast<uint32_t*>(p);  p += sizeof(uint32_t) * RR_FLT_MAXQ * RR_X3_MCAP;
-    s.count = reinterpret_cast<int32_t*>(p);    p += sizeof(int32_t) * RR_FLT_MAXQ;
-    s.tau = reinterpret_cast<uint32_t*>(p);     p += sizeof(uint32_t) * RR_FLT_MAXQ;
-    s.fb = reinterpret_cast<int32_t*>(p);       p += sizeof(int32_t) * RR_FLT_MAXQ;
-    s.eps = reinterpret_cast<float*>(p);        p += sizeof(float) * RR_FLT_MAXQ;
+    s.mtiles = reinterpret_cast<uint32_t*>(p);  p += sizeof(uint32_t) * RR_SEL_MAXQ * RR_X3_MCAP;
+    s.count = reinterpret_cast<int32_t*>(p);    p += sizeof(int32_t) * RR_SEL_MAXQ;
+    s.tau = reinterpret_cast<uint32_t*>(p);     p += sizeof(uint32_t) * RR_SEL_MAXQ;
+    s.fb = reinterpret_cast<int32_t*>(p);       p += sizeof(int32_t) * RR_SEL_MAXQ;
+    s.eps = reinterpret_cast<float*>(p);        p += sizeof(float) * RR_SEL_MAXQ;
     s.sc = reinterpret_cast<float*>(p);
     return s;
 }
 size_t rr_x3_scratch_bytes() {
-    return sizeof(uint32_t) * RR_FLT_MAXQ * RR_X3_MCAP + 4 * sizeof(int32_t) * RR_FLT_MAXQ +
-           sizeof(float) * (size_t)RR_FLT_MAXQ * RR_X3_MCAP * 16;
+    return sizeof(uint32_t) * RR_SEL_MAXQ * RR_X3_MCAP + 4 * sizeof(int32_t) * RR_SEL_MAXQ +
+           sizeof(float) * (size_t)RR_SEL_MAXQ * RR_X3_MCAP * 16;
 }
 void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st, const float* eps,
-                             const float* sigma) {
+                             const float* sigma, int nq_b, int64_t mmax_set_stride, int64_t smax_set_stride) {
     const rr_x3_scratch s = rr_x3_scratch_of(ix);
-    hipLaunchKernelGGL(rr_select_mtiles, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_gmax, ix->d_smax, pool,
-                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps, sigma);
+    hipLaunchKernelGGL(rr_select_mtiles, dim3(nq + nq_b), dim3(RR_SEL_THREADS), 0, st, G, ix->d_gmax, ix->d_smax, pool,
+                       s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps, sigma, nq, nq_b, mmax_set_stride,
+                       smax_set_stride);
 }
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st) {
@@ -1012,12 +1024,14 @@ static int rr_ensure_scratch(rr_index* ix, int nq) {
     RR_HIP_TRY(hipMalloc(&ix->d_sims, sizeof(float) * (size_t)nq * n_tiles * 64));
     // tile / group maxima: up to RR_FLT_MAXQ queries per launch (x4: per-M-tile maxima of the matrix-core scans)
     const size_t nm = nq >= RR_MFMA_MAXQ ? RR_FLT_MAXQ : nq;
-    RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * nm * n_tiles * 4));
+    // (the filter scan uses 2 words per 64-row tile and query: two sets of them fit, + one line per scan wave behind them)
+    const size_t gmax_words = nm * n_tiles * 4 + (size_t)RR_MAX_SCAN_WAVES * RR_FLT_MAXQ;
+    RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * gmax_words));
     // rr_scan_flt's store prefilter leaves the words of skipped tiles as they were: start from "-inf, no gaps" so that
     // a never-written word cannot open anything (stale words of earlier launches can only add rescoring work)
-    RR_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->d_gmax, 0x0000FF80, nm * n_tiles * 4, nullptr));
+    RR_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->d_gmax, 0x0000FF80, gmax_words, nullptr));
     RR_HIP_TRY(hipStreamSynchronize(nullptr));
-    RR_HIP_TRY(hipMalloc(&ix->d_smax, sizeof(uint32_t) * nm * groups_cap));
+    RR_HIP_TRY(hipMalloc(&ix->d_smax, sizeof(uint32_t) * 2 * nm * groups_cap));
     ix->scratch_q = nq;
     return RR_OK;
 }
@@ -1203,7 +1217,11 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
             n = left < RR_MFMA_MAXQ ? left : RR_MFMA_MAXQ;
             bool done = false;
             if (!f32_chain && !exact_scan && ix->scan_mode == RR_SCAN_MODE_DEFAULT) {
-                const int nf = left < RR_FLT_MAXQ ? left : RR_FLT_MAXQ;
+                // up to 128 queries per scan launch; 193 .. 256 remaining queries go as a PAIR of launches that share one
+                // selection / rescoring sequence (the second part must still use the 128-slot kernel: > 64 queries)
+                static const bool no_pair = getenv("RR_NO_PAIR") != nullptr;
+                int nf = left < RR_FLT_MAXQ ? left : RR_FLT_MAXQ;
+                if (!no_pair && left > RR_FLT_MAXQ + RR_MFMA_MAXQ) nf = left < RR_SEL_MAXQ ? left : RR_SEL_MAXQ;
                 rc = rr_dense_chunk_flt(ix, q, nf, pool, rows, scores, st);
                 if (rc != RR_FLT_NO_BOUND && rc != RR_FLT_SMALL) {
                     done = true;

@@ -605,15 +605,25 @@ static int rr_flt_ensure_shadow(rr_index* ix, hipStream_t st) {
 
 // SCAN_BF16: element type of the matrix the filter scan streams (the index's own bf16 rows, or the bf16 plane of an
 // fp32 index); ROWS_BF16: storage of the index, i.e. of the rows the candidates are rescored on.
-template <int NQ2, bool SCAN_BF16, bool ROWS_BF16>
-static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float* d_q, int nq, int pool, int64_t* d_rows,
-                                float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
+//
+// One scan launch ("set") = query planes + bounds, [store prefilter thresholds], the scan.  Sets 0 and 1 have their own
+// planes, eps / sigma entries (at RR_FLT_MAXQ * set) and tile / group maxima (at set * the strides below), so that two
+// scan launches can be followed by ONE selection + rescoring sequence over up to RR_SEL_MAXQ queries: the selection
+// kernels are latency-bound, one workgroup per query -- 128 of them fill half the CUs.
+static int64_t rr_flt_mmax_set_stride(const rr_scan_geom& G) { return (int64_t)2 * G.n_tiles * RR_FLT_MAXQ; }   // 4-byte words
+static int64_t rr_flt_smax_set_stride() { return (int64_t)RR_FLT_MAXQ * RR_MAX_SCAN_WAVES; }
+
+template <int NQ2, bool SCAN_BF16>
+static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const void* scan_mat, const float* d_q, int nq,
+                           int pool, rr_flt_bounds bounds, hipStream_t st, const float** sigma_out) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
-    const rr_scan_geom G = rr_flt_geom<NQ2, SCAN_BF16>(ix);
-    unsigned short* plane = reinterpret_cast<unsigned short*>(ix->d_qplanes);
+    unsigned short* plane = reinterpret_cast<unsigned short*>(ix->d_qplanes) + (size_t)set * RR_FLT_MAXQ * 384;
     const rr_x3_scratch X = rr_x3_scratch_of(ix);
-    hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, X.eps, bounds,
+    float* eps = X.eps + set * RR_FLT_MAXQ;
+    float* gmax = ix->d_gmax + set * rr_flt_mmax_set_stride(G);
+    uint32_t* smax = ix->d_smax + set * rr_flt_smax_set_stride();
+    hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, eps, bounds,
                        SCAN_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     // Store prefilter (bf16 stream, >= 2M rows): a 1/64 tile sample gives every query sigma = its m-th largest sampled
@@ -631,24 +641,34 @@ static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float*
         const int m = 16 + (4 * pool + stride - 1) / stride;
         if (!ix->d_flt_samp) {
             RR_HIP_TRY(hipMalloc((void**)&ix->d_flt_samp, sizeof(float) * (size_t)RR_FLT_SAMP_CAP * RR_FLT_MAXQ));
-            RR_HIP_TRY(hipMalloc((void**)&ix->d_flt_sigma, sizeof(float) * RR_FLT_MAXQ));
+            RR_HIP_TRY(hipMalloc((void**)&ix->d_flt_sigma, sizeof(float) * 2 * RR_FLT_MAXQ));
         }
+        float* sg = ix->d_flt_sigma + set * RR_FLT_MAXQ;
         hipLaunchKernelGGL((rr_flt_sample<NQ2>), dim3(256), dim3(512), 0, st, reinterpret_cast<const u32x4*>(scan_mat),
                            reinterpret_cast<const u32x4*>(plane), stride, (int)n_samp, ix->d_flt_samp);
         static const int force = getenv("RR_FLT_SIGMA_FORCE") ? atoi(getenv("RR_FLT_SIGMA_FORCE")) : 0;
-        hipLaunchKernelGGL(rr_flt_sigma, dim3(QN), dim3(256), 0, st, ix->d_flt_samp, (int)n_samp, QN, nq, m, X.eps,
-                           ix->d_flt_sigma, force);
-        sigma = ix->d_flt_sigma;
-        // the tile-maxima array is allocated for four words per (64-row tile, query); this scan uses two: the upper
-        // half holds the waves' dummy lines
-        dummy = reinterpret_cast<uint32_t*>(ix->d_gmax) + (size_t)2 * G.n_tiles * QN;
+        hipLaunchKernelGGL(rr_flt_sigma, dim3(QN), dim3(256), 0, st, ix->d_flt_samp, (int)n_samp, QN, nq, m, eps, sg, force);
+        sigma = sg;
+        // one line per scan wave behind the two sets of tile words (rr_ensure_scratch)
+        dummy = reinterpret_cast<uint32_t*>(ix->d_gmax) + (size_t)4 * G.n_tiles * RR_FLT_MAXQ;
     }
     const int slot = rr_scan_events_begin(ix, st);
     rr_scan_note(ix, 5, NQ2, nq, 1, SCAN_BF16 ? 2 : 4);
     hipLaunchKernelGGL((rr_scan_flt<NQ2, SCAN_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
-                       reinterpret_cast<const u32x4*>(plane), ix->d_gmax, ix->d_smax, X.eps, nq, sigma, dummy);
+                       reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy);
     rr_scan_events_end(ix, slot, st);
-    rr_launch_select_mtiles(ix, G, nq, pool, st, X.eps, sigma);
+    *sigma_out = sigma ? ix->d_flt_sigma : nullptr;        // (set 0's base: the selection adds set * RR_FLT_MAXQ itself)
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+// selection + rescoring + ordering + per-64 fallback over nq_a (+ nq_b) queries of one (two) scan launches
+template <bool ROWS_BF16>
+static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, int nq_a, int nq_b, int pool,
+                         int64_t* d_rows, float* d_scores, const float* sigma, hipStream_t st) {
+    const rr_x3_scratch X = rr_x3_scratch_of(ix);
+    const int nq = nq_a + nq_b;
+    rr_launch_select_mtiles(ix, G, nq_a, pool, st, X.eps, sigma, nq_b, rr_flt_mmax_set_stride(G), rr_flt_smax_set_stride());
     hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
                        X.mtiles, X.count, X.fb, X.sc);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st);
@@ -664,6 +684,29 @@ static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float*
     return RR_OK;
 }
 
+template <int NQ2, bool SCAN_BF16, bool ROWS_BF16>
+static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float* d_q, int nq, int pool, int64_t* d_rows,
+                                float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
+    const rr_scan_geom G = rr_flt_geom<NQ2, SCAN_BF16>(ix);
+    const float* sigma = nullptr;
+    const int rc = rr_flt_scan_set<NQ2, SCAN_BF16>(ix, 0, G, scan_mat, d_q, nq, pool, bounds, st, &sigma);
+    if (rc != RR_OK) return rc;
+    return rr_flt_finish<ROWS_BF16>(ix, G, d_q, nq, 0, pool, d_rows, d_scores, sigma, st);
+}
+
+// 129 .. 256 queries whose second part still fills a 128-slot launch (> 64 queries): two scan launches, one selection
+template <bool SCAN_BF16, bool ROWS_BF16>
+static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* d_q, int nq_a, int nq_b, int pool,
+                               int64_t* d_rows, float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
+    const rr_scan_geom G = rr_flt_geom<4, SCAN_BF16>(ix);
+    const float *sg0 = nullptr, *sg1 = nullptr;
+    int rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 0, G, scan_mat, d_q, nq_a, pool, bounds, st, &sg0);
+    if (rc != RR_OK) return rc;
+    rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 1, G, scan_mat, d_q + (int64_t)nq_a * ix->dim_pad, nq_b, pool, bounds, st, &sg1);
+    if (rc != RR_OK) return rc;
+    return rr_flt_finish<ROWS_BF16>(ix, G, d_q, nq_a, nq_b, pool, d_rows, d_scores, sg0, st);
+}
+
 int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                        float* d_scores, hipStream_t st) {
     // A small matrix has too few tile groups for the threshold to mean anything (every query would be
@@ -677,6 +720,18 @@ int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t
         return RR_FLT_NO_BOUND;
     const bool b = ix->dtype == RR_DTYPE_BF16;
     static const bool no_shadow = getenv("RR_NO_SHADOW") != nullptr;
+    if (nq > RR_FLT_MAXQ) {
+        // a pair of launches (the caller offers > 128 queries only when the second part is > 64: same kernel, same geometry)
+        const int nq_a = RR_FLT_MAXQ, nq_b = nq - RR_FLT_MAXQ;
+        if (!b && ix->use_shadow && !no_shadow) {
+            rc = rr_flt_ensure_shadow(ix, st);
+            if (rc != RR_OK) return rc;
+            if (ix->shadow_valid)
+                return rr_dense_pair_flt_t<true, false>(ix, ix->d_shadow, d_q, nq_a, nq_b, pool, d_rows, d_scores, nb, st);
+        }
+        return b ? rr_dense_pair_flt_t<true, true>(ix, ix->d_matrix, d_q, nq_a, nq_b, pool, d_rows, d_scores, nb, st)
+                 : rr_dense_pair_flt_t<false, false>(ix, ix->d_matrix, d_q, nq_a, nq_b, pool, d_rows, d_scores, nb, st);
+    }
     if (!b && ix->use_shadow && !no_shadow) {
         // fp32 storage: the scan streams the bf16 filter plane (half the bytes per launch; the approximate scores
         // and their bound are those of the on-the-fly rounding), the candidates are rescored on the fp32 rows

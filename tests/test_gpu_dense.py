@@ -503,3 +503,25 @@ def test_store_prefilter_of_the_filter_scan_stays_exact():
     assert_topk_matches(r1[0], s1[0], ref, pool)
     np.testing.assert_allclose(s1[0], scores[3], atol=2e-6, rtol=0)      # scores ~0.95: chain vs split-operand rounding
     ix.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("batch", [192, 193, 200, 256, 300, 449])
+def test_paired_scan_launches_share_one_selection(batch, dtype):
+    """193 .. 256 queries go as two filter-scan launches followed by ONE selection / rescoring sequence (the second
+    set's maxima, bounds and thresholds live behind the first's).  Every answer must still be the single-query scan's,
+    bit for bit -- including queries of the second set, ties across M-tiles, and batches that mix a pair with a tail."""
+    V = synth.unit_rows(400_000, 384, 177)
+    V[2000:2040] = V[15]
+    Q = synth.unit_rows(batch, 384, 178)
+    Q[3] = V[15]
+    Q[batch - 2] = V[15]                          # a tie-heavy query in the last launch too
+    ix = ProductIndex(V) if dtype == "f32" else ProductIndex.from_rows(V, dtype="bf16")
+    rows, scores = ix.dense_topk(Q, 150)
+    for i in sorted({0, 3, 127, 128, 129, 191, 192, batch - 2, batch - 1} & set(range(batch))):
+        r1, s1 = ix.dense_topk(Q[i:i + 1], 150)
+        assert np.array_equal(r1[0], rows[i]), i
+        assert np.array_equal(s1[0].view(np.uint32), scores[i].view(np.uint32)), i
+    if dtype == "f32":
+        check_against_oracle(V, Q[[0, 130, batch - 1]], 150, index=ix)
+    ix.close()
