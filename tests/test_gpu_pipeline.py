@@ -338,3 +338,34 @@ def test_token_lists_are_staged_on_every_call(world):
     flat = (np.concatenate(lists).astype(np.int32), np.array([0, len(lists[0]), len(lists[0]) + len(lists[1])], np.int32))
     d = engine.searcher.search_batch(Q, flat, 20, 0, w)
     assert np.array_equal(d.bm25_raw, c.bm25_raw)
+
+
+def test_module_level_run_search_shim_takes_the_eval_harness_call_shape(world, tmp_path):
+    """evals/performance_metrics.py:266 calls `search_function(query, **config)` with the keys of
+    evals/test_queries.py:255-312 (incl. use_snips / max_scan); the UI calls it positionally
+    (app/app_product_search.py:402).  frontend.run_search is that function over one cached engine."""
+    from review_recommender_amd import artifacts, frontend
+
+    class Enc:                                   # the reference's tests mock the encoder the same way
+        def encode(self, texts, normalize_embeddings=True):
+            return synth.unit_rows(len(texts), 384, 321)
+
+    artifacts.save_artifacts(tmp_path, world["meta"], world["V"], world["blob"])
+    eng = frontend.configure(data_dir=tmp_path, encoder=Enc(), cross_encoder=FakeCrossEncoder())
+    assert frontend.engine() is eng
+    benchmark_config = {"k": 50, "rerank_k": 20, "w_dense": 0.4, "w_bm25": 0.2, "w_rerank": 0.3, "w_prior": 0.1,
+                        "w_best": 0.0, "prior_C": 20.0, "use_snips": False, "max_scan": 50000, "min_reviews": 5,
+                        "gate_penalty": 0.5}                       # "Hybrid + Rerank", evals/test_queries.py:297-311
+    a, snips, dbg = frontend.run_search("yellow cat socks", **benchmark_config)
+    b, _, _ = frontend.run_search("yellow cat socks", 50, 20, 0.4, 0.2, 0.3, 0.1, 0.0, 20.0, False, 50000, 5, 0.5)
+    assert a.equals(b) and len(a) == 50 and snips == {} and dbg["pool"] == 150
+    ce = FakeCrossEncoder()
+    qv = synth.unit_rows(1, 384, 321)[0]
+    from oracle.primitives import l2_normalize
+    want, _, _, _ = run_search_oracle(query="yellow cat socks", qvec=qv, meta=world["meta"], V=l2_normalize(world["V"]),
+                                      bm25=world["ora_bm25"], bm25_skus=world["blob"]["skus"],
+                                      rerank_fn=(lambda pairs: ce.predict(pairs)),
+                                      **{k_: v for k_, v in benchmark_config.items() if k_ not in ("use_snips", "max_scan")})
+    assert a["sku"].tolist()[:10] == want["sku"].tolist()[:10]
+    np.testing.assert_allclose(a["_final"].values, want["_final"].values, atol=TOL, rtol=0)
+    assert list(a.columns) == list(want.drop(columns=["_row"]).columns)
