@@ -60,6 +60,8 @@ struct rr_index {
     // rounds to bf16 anyway); candidates are rescored on the fp32 rows.  Built lazily, dropped by any write to the matrix.
     float* d_flt_samp = nullptr;     // [<= RR_FLT_SAMP_CAP][RR_FLT_MAXQ] sampled tile maxima (store prefilter of rr_scan_flt)
     float* d_flt_sigma = nullptr;    // [RR_FLT_MAXQ] per-query store threshold
+    uint32_t* d_flt_prog = nullptr;  // [2][n_waves] progress words of the two-set scan launch (pairs of waves keep in step)
+    uint32_t flt_seq = 0;            // launch counter of the two-set scan (epoch of the progress words)
     unsigned short* d_shadow = nullptr;
     bool shadow_valid = false;
     int32_t use_shadow = 1;

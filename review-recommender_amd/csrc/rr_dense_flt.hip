@@ -121,6 +121,21 @@ __global__ __launch_bounds__(256) void rr_row_norm_max(const void* __restrict__ 
 }
 
 // ------------------------------------------------------------------ the filter scan
+__device__ __forceinline__ float rr_vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float rr_vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t rr_cvt_u32_sat(float x) {       // saturating, NaN -> 0 (a C++ cast is undefined there)
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 // RR_FLT_THREADS(NQ2): workgroup size.  Four query tiles want 270 registers for a B-fragment lead of two
 // K-steps; RR_FLT_ONE_WAVE=1 builds that variant (one wave per SIMD, the whole register file, lead 2):
 // measured equal to two waves per SIMD with lead 1 (scan(128 q) / scan(32 q) = 1.14 either way), so off.
@@ -130,20 +145,49 @@ __global__ __launch_bounds__(256) void rr_row_norm_max(const void* __restrict__ 
 #endif
 // DBG != 0: timing-only ablations (rr_debug_scan_flt, tools/flt_ablate.py; wrong results): bit 0 no epilogue
 // (accumulators kept alive), bit 1 no B-fragment reads, bit 2 no MFMAs, bit 3 no lane swaps / conversions, bit 4 no M-tile maxima stores.
-template <int NQ2, bool A_BF16, int DBG = 0>
+//
+// DUAL: ONE launch serves TWO query sets (2 x 128 queries) with one pass over the matrix out of HBM.  The grid is still
+// one workgroup per CU, but a workgroup belongs to a set (its LDS holds that set's planes) and the row runs are twice
+// as long: workgroups b and b + 8 -- consecutive workgroups of the SAME XCD under the round-robin dispatch -- walk the
+// same runs for set 0 and set 1.  Whichever of the two is ahead pulls a line into that XCD's L2 (or the die's Infinity
+// Cache); the other finds it there, gets its data sooner and catches up, so the pair stays within a burst of each
+// other and the matrix leaves HBM once for 256 queries.  Set 1's planes / eps / sigma sit RR_FLT_MAXQ entries behind
+// set 0's, its tile and group maxima at the set strides of rr_flt_scan_set.
+template <int NQ2, bool A_BF16, int DBG = 0, bool DUAL = false>
 __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 1 : 2)) void rr_scan_flt(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [32*NQ2][48] units
     float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq,
     const float* __restrict__ sigma,      // [32*NQ2] store prefilter (null: every tile word is stored), see rr_flt_sample
-    uint32_t* __restrict__ dummy) {       // [n_waves][32*NQ2] lines that absorb the skipped stores
+    uint32_t* __restrict__ dummy,         // [n_waves][32*NQ2] lines that absorb the skipped stores
+    int nq_b = 0, int64_t gmax_set_stride = 0,        // DUAL: queries of set 1, words between the sets' tile maxima,
+    uint32_t* __restrict__ prog = nullptr, uint32_t seq = 0,     // [2][n_waves] progress words, launch number << 16
+    int tune = 0) {                       // experiment switches (RR_FLT_TUNE): see rr_flt_tune()
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
+    int wg = blockIdx.x;                               // workgroup's place in the row partition
+    int set = 0;
+    if (DUAL) {
+        set = (wg >> 3) & 1;
+        wg = ((wg >> 4) << 3) | (wg & 7);
+        plane += (size_t)set * (RR_FLT_MAXQ * RR_X3_UNITS);
+        eps += set * RR_FLT_MAXQ;
+        if (sigma) sigma += set * RR_FLT_MAXQ;
+        gmax += set * gmax_set_stride;
+        smax += (size_t)set * RR_FLT_MAXQ * RR_MAX_SCAN_WAVES;
+        nq = set ? nq_b : nq;
+    }
     constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
     constexpr int SEGS = A_BF16 ? 1 : 2;              // ring segments (24 units per lane) per 32-row M-tile
     constexpr int STEPS = A_BF16 ? 24 : 12;           // K-steps (16 dims) per ring segment
     __shared__ u32x4 qs[QN * RR_FLT_QSTRIDE];
     __shared__ float sg[QN];
+    // The two waves of a SIMD take turns in the K-loop (see `paired` below): K-loops each wave has finished, and the
+    // SIMD each wave sits on (HW_REG_HW_ID bits 5:4)
+    __shared__ int kdone[THREADS / 64];
+    __shared__ int simd_of[THREADS / 64];
     const int tid = threadIdx.x;
+    if (tid < THREADS / 64) kdone[tid] = 0;
+    if ((tid & 63) == 0) simd_of[tid >> 6] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
     for (int i = tid; i < QN * RR_X3_UNITS; i += THREADS)
         qs[(i / RR_X3_UNITS) * RR_FLT_QSTRIDE + (i % RR_X3_UNITS)] = plane[i];
     for (int i = tid; i < QN; i += THREADS) sg[i] = sigma ? sigma[i] : -INFINITY;
@@ -152,11 +196,27 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     const int lane = tid & 63;
     const int c = lane & 31;                          // MFMA: A row / B and C column
     const int h = lane >> 5;                          //       k half (A, B); C rows 8g + 4h + i
-    const int64_t wave = (int64_t)blockIdx.x * (THREADS / 64) + (tid >> 6);
-    if (wave >= G.n_waves) return;
+    const int64_t wave = (int64_t)wg * (THREADS / 64) + (tid >> 6);
+    const int wid = tid >> 6, pw = wid ^ (THREADS / 128);      // this wave and the one expected on the same SIMD
+    if (wave >= G.n_waves) {
+        if (lane == 0) kdone[wid] = 0x7FFFFFFF;                // nobody waits for a wave without rows
+        return;
+    }
+    // Two waves per SIMD left alone fall into step: both in the K-loop (sharing the matrix pipe), then both in the
+    // epilogue (sharing the vector issue, matrix pipe idle) -- measured with in-kernel stamps: K-loop 6.9 k cycles,
+    // epilogue 5.4 k per M-tile, of 3.1 k MFMA cycles each.  So they take turns: K-loop i of the second wave starts when
+    // K-loop i of the first is done, K-loop i + 1 of the first when K-loop i of the second is done; each epilogue then
+    // runs in the issue gaps of the other wave's MFMAs.  (A wave waits on the LDS counter of its partner; a partner on
+    // another SIMD -- not how workgroups are placed, but not a contract either -- or one that stops counting switches it off.)
+    bool paired = (tune & 8) && THREADS == 512 && simd_of[wid] == simd_of[pw];
+    const int seat = wid >= THREADS / 128 ? 1 : 0;
     const int64_t t0 = wave * G.tiles_per_wave;
     const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
     const int64_t m0 = t0 * 2, m1 = t1 * 2;           // 32-row M-tiles of this wave
+    const bool second = (tid >> 6) >= THREADS / 128;  // the second wave of its SIMD (waves w and w + 4 share one)
+    if ((tune & 2) && second) {                       // start half an M-tile late: epilogue (VALU) against the other's K-loop (MFMA)
+        __builtin_amdgcn_s_sleep(100);               // 6400 cycles
+    }
 
     const int lrow = lane & 15, lpc = lane >> 4;      // load order: row of the 16-row half, 16-B piece
     const u32x4* px;
@@ -165,6 +225,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
         int64_t mt = m0 + seg / SEGS;
         const int p = (int)(seg % SEGS);
         mt = mt < m1 ? mt : m1 - 1;                   // (past the end: redundant re-loads, never used)
+        if (DBG & 64) mt = m0 + (mt & 1);             // timing only: every wave re-reads its first two M-tiles (cache hits)
         int64_t rx = mt * 32 + lrow, ry = rx + 16;
         rx = rx < G.n_rows ? rx : G.n_rows - 1;
         ry = ry < G.n_rows ? ry : G.n_rows - 1;
@@ -190,7 +251,23 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     // stores cost) drop with the lines skipped.
     uint32_t pend_keep = 0xFFFFFFFFu;                 // bit j: the pending word of group j is wanted (wave-uniform)
     uint32_t junk = 0u;                               // destination of the loads that stand in for skipped stores
-    uint32_t* const my_dummy = dummy ? dummy + (size_t)wave * QN : nullptr;
+    uint32_t* const my_dummy = dummy ? dummy + ((size_t)set * G.n_waves + wave) * QN : nullptr;
+    // DUAL: the pair (this wave, the wave of the other set with the same run) only shares its reads while the two stay
+    // within the L2's retention (~ a tile) of each other; once they drift further both miss and nothing pulls them
+    // back.  So each wave publishes the M-tile it is in (lane 32 of group 0's tile-word store instruction: no extra
+    // vector-memory operation for the counted ring waits) and, at the end of that M-tile, the one that is ahead
+    // waits -- a bounded number of scalar polls; a wave whose partner never shows up stops looking -- until the
+    // other has reached the same M-tile.
+    uint32_t* const my_prog = DUAL && prog ? prog + (size_t)set * G.n_waves + wave : nullptr;
+    const uint32_t* partner_prog = nullptr;
+    bool coupled = false;
+    if (DUAL && prog) {
+        const uint64_t pa = reinterpret_cast<uint64_t>(prog + (size_t)(set ^ 1) * G.n_waves + wave);
+        const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)pa), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
+        partner_prog = reinterpret_cast<const uint32_t*>(((uint64_t)hi32 << 32) | lo32);
+        coupled = true;
+    }
+    const uint32_t code_shift = 16u + 4u * (uint32_t)h;     // this k half encodes M-tiles h and 2 + h (bits 16 + 4 g)
     const float step = rr_flt_gap_step(eps, nq);      // resolution of the 8-row gaps (half the smallest eps of the launch)
     const float inv_step = step > 0.f ? 0.9999f / step : 0.f;    // (0.9999: the decoded bound never rounds below the maximum)
 #pragma unroll
@@ -233,13 +310,33 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
         }
     }
 
+    uint64_t dbg_kloop = 0, dbg_epi = 0, dbg_wait = 0;      // DBG & 128: shader cycles of this wave in the K-loops (ring waits
+    const uint64_t dbg_t0 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;   // included), in the epilogues, in the ring waits
 #pragma unroll 1
     for (int64_t mt = m0; mt < m1; ++mt) {
+        uint64_t ts0 = 0;
+        if (DBG & 128) ts0 = __builtin_amdgcn_s_memtime();
         f32x16 acc[NQ2];
 #pragma unroll
         for (int t = 0; t < NQ2; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        if (paired) {
+            const int need = (int)(mt - m0) + seat;
+            int spins = 0;
+            while (__hip_atomic_load(&kdone[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                if (++spins > 200000) {        // (a safety net, never seen: ~20 ms)
+                    paired = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (tune & 4) {                    // K-loop: the first wave of the SIMD owns the matrix pipe, the second takes what is left
+            if (second) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        }
+        if (tune & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int p = 0; p < SEGS; ++p) {
             seg_ptrs((mt - m0) * SEGS + p + 1);           // the bursts of this segment refill the ring for the next
@@ -247,7 +344,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
             for (int s = 0; s < STEPS; ++s) {
                 const int cb = (p * STEPS + s) & 1;
                 const int s2 = (s + 1) % STEPS;                           // the K-step being prepared
-                constexpr int LEAD = (NQ2 >= 4 && THREADS == 512) ? 1 : 2;   // K-steps of B-fragment prefetch (4 tiles x 2 waves/SIMD: no registers for 2)
+                constexpr int LEAD = (NQ2 >= 4 && THREADS == 512) ? 1 : 2;   // K-steps of B-fragment prefetch (2 measured no faster at 4 tiles x 2 waves/SIMD)   // K-steps of B-fragment prefetch (4 tiles x 2 waves/SIMD: no registers for 2)
                 const int kk3 = A_BF16 ? (s + LEAD) % 24 : (12 * p + s + LEAD) % 24;   // K-step of the row LEAD steps ahead
                 const bool swap = A_BF16 ? (s2 % 2 == 0) : true;          // it starts a new pair of the ring
                 const int np = A_BF16 ? s2 / 2 : s2;
@@ -257,8 +354,11 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                     // ring waits and deferred maxima stores exactly as in rr_scan_x3w
                     // (younger than what the wait needs: the other half's burst, and for the segment's second wait
                     //  the NQ2 maxima stores issued during the K-step after the first burst, see below)
+                    uint64_t tw0 = 0;
+                    if (DBG & 128) tw0 = __builtin_amdgcn_s_memtime();
                     if (p == 0 && (np == 0 || s > STORE_STEP) && !(DBG & 16)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + NQ2) : "memory");
                     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    if (DBG & 128) dbg_wait += __builtin_amdgcn_s_memtime() - tw0;
 #pragma unroll
                     for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(a[(np / 6) * 12 + j]));
                 }
@@ -292,7 +392,16 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                     // into a saturated read stream.
                     if (p == 0 && s == STORE_STEP && !(DBG & 16)) {
                         const int64_t mprev = mt > m0 ? mt - 1 : mt;
-                        if (my_dummy && !((pend_keep >> j) & 1u)) {
+                        if (DUAL && j == 0 && my_prog) {
+                            // ONE store instruction: group 0's tile words from the h == 0 lanes (if wanted) and this
+                            // wave's progress word from lane 32
+                            const bool want = !my_dummy || (pend_keep & 1u);
+                            if ((h == 0 && want) || lane == 32) {
+                                uint32_t* dst = lane == 32 ? my_prog : reinterpret_cast<uint32_t*>(gmax) + mprev * QN + c;
+                                const int64_t in_run = mt - m0 + 1;
+                                *dst = lane == 32 ? seq + (uint32_t)(in_run < 65535 ? in_run : 65535) : pend[0];
+                            }
+                        } else if (my_dummy && !((pend_keep >> j) & 1u)) {
                             // skipped line: a LOAD of this wave's own (cache-resident) line keeps the count of vector-memory
                             // operations in flight that the ring waits assume; a store to such a line still went out to
                             // HBM (PMC WRITE_SIZE unchanged at 165 MB per launch: full-line writes are streamed through)
@@ -316,45 +425,65 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                 for (int e = 0; e < 16; ++e) asm volatile("" :: "v"(acc[t][e]));
             continue;
         }
+        if (tune & (4 | 16)) __builtin_amdgcn_s_setprio(0);
+        if (THREADS == 512 && lane == 0) __hip_atomic_store(&kdone[wid], (int)(mt - m0) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint64_t ts1 = 0;
+        if (DBG & 128) {
+            ts1 = __builtin_amdgcn_s_memtime();
+            dbg_kloop += ts1 - ts0;
+        }
         // lane (c, h), register 4g + i: row 8g + 4h + i of the M-tile, query 32t + c
         const int64_t rbase = mt * 32 + 4 * h;
-        const bool full = mt * 32 + 32 <= G.n_rows;
+        if (mt * 32 + 32 > G.n_rows) {                // the matrix's last, short M-tile: rows past the end (and NaNs) -> -inf
+#pragma unroll
+            for (int t = 0; t < NQ2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                    v = rr_x3_canon(v, rbase + 8 * g, G.n_rows);
+                    acc[t][4 * g] = v.x; acc[t][4 * g + 1] = v.y; acc[t][4 * g + 2] = v.z; acc[t][4 * g + 3] = v.w;
+                }
+        }
         uint32_t keep_now = 0u;
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
-            // maxima of the four 8-row M-tiles (rows 8g .. 8g + 7 = registers 4g .. 4g + 3 of both k halves)
-            float m8[4];
+            // (v_max_f32 / v_max3_f32 spelled out: fmaxf() brings a canonicalising v_max x, x, x per operand with it --
+            //  three instructions per maximum; like fmaxf they return the other operand for a NaN)
+            // lane-local maxima of the four 8-row M-tiles' rows in this k half (registers 4g .. 4g + 3)
+            float p8[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-                if (!full) v = rr_x3_canon(v, rbase + 8 * g, G.n_rows);            // (fmaxf drops a NaN by itself)
-                m8[g] = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-            }
-            // the other k half's rows (lane l ^ 32)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m8[g]), __float_as_uint(m8[g]), false, false);
-                m8[g] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-            }
+            for (int g = 0; g < 4; ++g) p8[g] = rr_vmax3(acc[t][4 * g], acc[t][4 * g + 1], rr_vmax(acc[t][4 * g + 2], acc[t][4 * g + 3]));
+            // the other k half's rows sit in lane l ^ 32.  v_permlane32_swap(x, y) leaves x = {x.lo, y.lo}, y = {x.hi, y.hi},
+            // so max(x, y) of (p8[0], p8[1]) is the whole M-tile 0 in the lower 32 lanes and M-tile 1 in the upper 32:
+            // lane half h ends up with the maxima of M-tiles h (u) and 2 + h (w) of query column c -- two swaps, not four
+            const auto r01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p8[0]), __float_as_uint(p8[1]), false, false);
+            const auto r23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p8[2]), __float_as_uint(p8[3]), false, false);
+            const float u = rr_vmax(__uint_as_float(r01[0]), __uint_as_float(r01[1]));
+            const float w = rr_vmax(__uint_as_float(r23[0]), __uint_as_float(r23[1]));
+            const float mh = rr_vmax(u, w);
+            const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
+            const float m32 = rr_vmax(__uint_as_float(rm[0]), __uint_as_float(rm[1]));      // the tile maximum, in both halves
+            gm[t] = rr_vmax(gm[t], m32);
+            const bool kept = __ballot(m32 >= sg[32 * t + c]) != 0ull;                      // (wave-uniform)
+            keep_now |= (kept ? 1u : 0u) << t;
+            if (my_dummy && !kept) continue;                                                 // its word is never stored: no codes
             // 4 bytes per (32-row tile, query): the tile maximum as bf16 ROUNDED UP + for each 8-row M-tile how far
             // below it its own maximum sits, in units of `step`, ROUNDED DOWN to a 4-bit code (0..12 steps, then
             // >= 16, 24, 40).  The filter only asks "can this M-tile hold a score >= threshold": the decoded value
             // max_up - steps(code) * step is an upper bound of the M-tile's maximum.
-            const float m32 = fmaxf(fmaxf(m8[0], m8[1]), fmaxf(m8[2], m8[3]));
-            gm[t] = fmaxf(gm[t], m32);
-            keep_now |= (__ballot(m32 >= sg[32 * t + c]) != 0ull ? 1u : 0u) << t;
             const uint32_t b = __float_as_uint(m32);
             uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);           // toward +inf; +-inf stay
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float gap = (m32 - m8[g]) * inv_step;                          // >= 0, in steps; inf - inf = NaN -> code 0
-                uint32_t code = (uint32_t)fminf(gap, 12.f);                          // 0 .. 12 steps exactly (rounded down), then
-                code = gap >= 16.f ? 13u : code;                                     // "at least 16 | 24 | 40 steps" (RR_FLT_GAP_STEPS):
-                code = gap >= 24.f ? 14u : code;                                     // an ordinary M-tile next to a top row sits ~30 eps
-                code = gap >= 40.f ? 15u : code;                                     // below it and must not be opened with it
-                code = gap == gap ? code : 0u;
-                word |= code << (16 + 4 * g);
-            }
+            // codes of this half's two M-tiles: min(floor(gap), 12) + [gap >= 16] + [gap >= 24] + [gap >= 40]
+            // (v_cvt_u32_f32 saturates and turns NaN -- inf - inf -- into 0; the comparisons are false for NaN: code 0)
+            const float gu = (m32 - u) * inv_step, gw = (m32 - w) * inv_step;        // >= 0, in steps
+            uint32_t cu = rr_cvt_u32_sat(gu), cw = rr_cvt_u32_sat(gw);
+            cu = cu < 12u ? cu : 12u;
+            cw = cw < 12u ? cw : 12u;
+            cu += (gu >= 16.f ? 1u : 0u) + (gu >= 24.f ? 1u : 0u) + (gu >= 40.f ? 1u : 0u);
+            cw += (gw >= 16.f ? 1u : 0u) + (gw >= 24.f ? 1u : 0u) + (gw >= 40.f ? 1u : 0u);
+            const uint32_t mine = (cu | (cw << 8)) << code_shift;                    // M-tile g's code at bit 16 + 4 g
+            const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+            word |= rc[0] | rc[1];
             pend[t] = word;
         }
         pend_keep = keep_now;
@@ -370,9 +499,30 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                 }
             }
         }
+        if (DBG & 128) dbg_epi += __builtin_amdgcn_s_memtime() - ts1;
+        if (DUAL && coupled) {
+            const int64_t in_run = mt - m0 + 1;
+            const uint32_t mine = seq + (uint32_t)(in_run < 65535 ? in_run : 65535);
+            uint32_t theirs;
+            int spins = 0;
+            for (;;) {
+                asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(theirs) : "s"(partner_prog) : "memory");
+                if ((int32_t)(theirs - mine) >= 0) break;
+                if (++spins >= 64) {            // ~40 us: the partner is not resident (or not on this XCD): go alone
+                    coupled = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
     }
+    if (THREADS == 512 && lane == 0) __hip_atomic_store(&kdone[wid], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
     asm volatile("" :: "v"(junk));
+    if ((DBG & 128) && prog && lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(prog) + wave * 4;
+        o[0] = dbg_kloop; o[1] = dbg_epi; o[2] = dbg_wait; o[3] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    }
     if (h == 0) {
         // groups of this wave that hold no tile (a short last run): key 0 = "nothing here"
         const int cg = (int)G.tiles_per_group;
@@ -559,16 +709,19 @@ static int rr_flt_get_bounds(rr_index* ix, hipStream_t st, rr_flt_bounds* out) {
     return RR_OK;
 }
 
+// dual: the geometry of a two-set launch (rr_scan_flt<.., DUAL>): half the resident waves per set, runs twice as long,
+// eighth runs as selection groups (the same number and size of groups as a single-set launch)
 template <int NQ2, bool A_BF16>
-static rr_scan_geom rr_flt_geom(rr_index* ix) {
+static rr_scan_geom rr_flt_geom(rr_index* ix, bool dual = false) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     static int waves = 0;
     if (!waves) waves = rr_resident_waves((const void*)rr_scan_flt<NQ2, A_BF16>, THREADS, ix->device);
-    rr_scan_geom G = rr_make_geom(ix, waves / 4);
+    rr_scan_geom G = rr_make_geom(ix, dual ? waves / 8 : waves / 4);
     G.qs = 32 * NQ2;
     G.mm_pairs = 3;
     // selection groups = quarter runs: ~4x fewer tile maxima to open per group (at most 8192 groups)
-    G.gpw = RR_MAX_SCAN_WAVES / G.n_waves < 4 ? (RR_MAX_SCAN_WAVES / G.n_waves < 1 ? 1 : RR_MAX_SCAN_WAVES / G.n_waves) : 4;
+    const int gcap = dual ? 8 : 4;
+    G.gpw = RR_MAX_SCAN_WAVES / G.n_waves < gcap ? (RR_MAX_SCAN_WAVES / G.n_waves < 1 ? 1 : RR_MAX_SCAN_WAVES / G.n_waves) : gcap;
     if (G.gpw > G.tiles_per_wave) G.gpw = (int32_t)G.tiles_per_wave;
     G.tiles_per_group = (G.tiles_per_wave + G.gpw - 1) / G.gpw;
     G.gpw = (int32_t)((G.tiles_per_wave + G.tiles_per_group - 1) / G.tiles_per_group);     // no empty trailing groups
@@ -603,6 +756,11 @@ static int rr_flt_ensure_shadow(rr_index* ix, hipStream_t st) {
     return RR_OK;
 }
 
+static int rr_flt_tune() {
+    static const int t = getenv("RR_FLT_TUNE") ? atoi(getenv("RR_FLT_TUNE")) : 0;
+    return t;
+}
+
 // SCAN_BF16: element type of the matrix the filter scan streams (the index's own bf16 rows, or the bf16 plane of an
 // fp32 index); ROWS_BF16: storage of the index, i.e. of the rows the candidates are rescored on.
 //
@@ -615,7 +773,8 @@ static int64_t rr_flt_smax_set_stride() { return (int64_t)RR_FLT_MAXQ * RR_MAX_S
 
 template <int NQ2, bool SCAN_BF16>
 static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const void* scan_mat, const float* d_q, int nq,
-                           int pool, rr_flt_bounds bounds, hipStream_t st, const float** sigma_out) {
+                           int pool, rr_flt_bounds bounds, hipStream_t st, const float** sigma_out,
+                           bool launch_scan = true) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
     unsigned short* plane = reinterpret_cast<unsigned short*>(ix->d_qplanes) + (size_t)set * RR_FLT_MAXQ * 384;
@@ -652,12 +811,17 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
         // one line per scan wave behind the two sets of tile words (rr_ensure_scratch)
         dummy = reinterpret_cast<uint32_t*>(ix->d_gmax) + (size_t)4 * G.n_tiles * RR_FLT_MAXQ;
     }
+    *sigma_out = sigma ? ix->d_flt_sigma : nullptr;        // (set 0's base: the selection adds set * RR_FLT_MAXQ itself)
+    if (!launch_scan) {                                    // the caller scans both sets in one launch
+        RR_HIP_TRY(hipGetLastError());
+        return RR_OK;
+    }
     const int slot = rr_scan_events_begin(ix, st);
     rr_scan_note(ix, 5, NQ2, nq, 1, SCAN_BF16 ? 2 : 4);
     hipLaunchKernelGGL((rr_scan_flt<NQ2, SCAN_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
-                       reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy);
+                       reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy, 0, (int64_t)0,
+                       (uint32_t*)nullptr, 0u, rr_flt_tune());
     rr_scan_events_end(ix, slot, st);
-    *sigma_out = sigma ? ix->d_flt_sigma : nullptr;        // (set 0's base: the selection adds set * RR_FLT_MAXQ itself)
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
@@ -698,12 +862,38 @@ static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float*
 template <bool SCAN_BF16, bool ROWS_BF16>
 static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* d_q, int nq_a, int nq_b, int pool,
                                int64_t* d_rows, float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
-    const rr_scan_geom G = rr_flt_geom<4, SCAN_BF16>(ix);
+    // bf16 stream: both sets in ONE launch, the matrix leaves HBM once for the 256 queries (rr_scan_flt<.., DUAL>).
+    // RR_NO_DUAL=1: two launches back to back (A/B).  An fp32 stream (no plane) keeps the two launches: its ring is
+    // two segments per M-tile and the pair's lock-step window would be twice as wide.
+    static const bool no_dual = getenv("RR_NO_DUAL") != nullptr;
+    const bool dual = SCAN_BF16 && !no_dual;
+    const rr_scan_geom G = rr_flt_geom<4, SCAN_BF16>(ix, dual);
     const float *sg0 = nullptr, *sg1 = nullptr;
-    int rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 0, G, scan_mat, d_q, nq_a, pool, bounds, st, &sg0);
+    int rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 0, G, scan_mat, d_q, nq_a, pool, bounds, st, &sg0, !dual);
     if (rc != RR_OK) return rc;
-    rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 1, G, scan_mat, d_q + (int64_t)nq_a * ix->dim_pad, nq_b, pool, bounds, st, &sg1);
+    rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 1, G, scan_mat, d_q + (int64_t)nq_a * ix->dim_pad, nq_b, pool, bounds, st, &sg1, !dual);
     if (rc != RR_OK) return rc;
+    if (dual) {
+        constexpr int THREADS = RR_FLT_THREADS(4);
+        const int nb = (G.n_waves + THREADS / 64 - 1) / (THREADS / 64);        // workgroups per set
+        const dim3 grid(((nb + 7) / 8) * 16), block(THREADS);
+        const rr_x3_scratch X = rr_x3_scratch_of(ix);
+        uint32_t* dummy = sg0 ? reinterpret_cast<uint32_t*>(ix->d_gmax) + (size_t)4 * G.n_tiles * RR_FLT_MAXQ : nullptr;
+        const int slot = rr_scan_events_begin(ix, st);
+        rr_scan_note(ix, 5, 8, nq_a + nq_b, 1, 2);
+        static const bool no_couple = getenv("RR_NO_COUPLE") != nullptr;
+        if (!ix->d_flt_prog) {
+            RR_HIP_TRY(hipMalloc((void**)&ix->d_flt_prog, sizeof(uint32_t) * 2 * RR_MAX_SCAN_WAVES));
+            RR_HIP_TRY(hipMemsetAsync(ix->d_flt_prog, 0, sizeof(uint32_t) * 2 * RR_MAX_SCAN_WAVES, st));
+        }
+        ix->flt_seq = (ix->flt_seq + 1) & 0x7FFFu;
+        hipLaunchKernelGGL((rr_scan_flt<4, SCAN_BF16, 0, true>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, sg0, dummy,
+                           nq_b, rr_flt_mmax_set_stride(G), no_couple ? (uint32_t*)nullptr : ix->d_flt_prog,
+                           (uint32_t)(ix->flt_seq + 1) << 16, rr_flt_tune());
+        rr_scan_events_end(ix, slot, st);
+        RR_HIP_TRY(hipGetLastError());
+    }
     return rr_flt_finish<ROWS_BF16>(ix, G, d_q, nq_a, nq_b, pool, d_rows, d_scores, sg0, st);
 }
 
@@ -761,6 +951,11 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     constexpr int THREADS = RR_FLT_THREADS(4);
     const rr_scan_geom G = rr_flt_geom<4, PLANE>(ix);
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
+    unsigned long long* d_stamps = nullptr;
+    if (DBG & 128) {
+        if (hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 4 * RR_MAX_SCAN_WAVES) != hipSuccess) return -1.f;
+        hipMemset(d_stamps, 0, sizeof(unsigned long long) * 4 * RR_MAX_SCAN_WAVES);
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -770,7 +965,8 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
         hipLaunchKernelGGL((rr_scan_flt<4, PLANE, DBG>), grid, block, 0, st,
                            reinterpret_cast<const u32x4*>(PLANE ? (const void*)ix->d_shadow : (const void*)ix->d_matrix), G,
                            reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128,
-                           (const float*)nullptr, (uint32_t*)nullptr);
+                           (const float*)nullptr, (uint32_t*)nullptr, 0, (int64_t)0, reinterpret_cast<uint32_t*>(d_stamps), 0u,
+                           rr_flt_tune());
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
         float ms = 0.f;
@@ -779,6 +975,18 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    if (DBG & 128) {        // per-wave shader cycles of the last launch: K-loops, epilogues, ring waits, whole scan
+        std::vector<unsigned long long> h((size_t)4 * G.n_waves);
+        hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        hipFree(d_stamps);
+        double sum[4] = {0, 0, 0, 0};
+        for (int w = 0; w < G.n_waves; ++w)
+            for (int k = 0; k < 4; ++k) sum[k] += (double)h[(size_t)4 * w + k];
+        const double tiles = (double)((G.n_rows + 31) / 32);
+        fprintf(stderr, "[flt stamps] per M-tile and wave, shader cycles: K-loop %.0f (of which ring waits %.0f), epilogue %.0f; "
+                        "whole scan per wave %.0f cycles, %d waves\n", sum[0] / tiles, sum[2] / tiles, sum[1] / tiles,
+                sum[3] / G.n_waves, G.n_waves);
+    }
     return total / reps;
 }
 
@@ -805,6 +1013,21 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
         case 64:
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
             *out_ms = rr_debug_time_flt<0, true>(ix, st, reps);
+            break;
+        // 128: the full kernel over the plane with every ring load served from cache (same code, same registers: only
+        // the addresses differ) = the pace of everything but HBM
+        case 128:
+            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
+            *out_ms = rr_debug_time_flt<64, true>(ix, st, reps);
+            break;
+        // 256 / 320: in-kernel s_memtime stamps (K-loop / ring waits / epilogue per wave, printed to stderr), over HBM / from cache
+        case 256:
+            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
+            *out_ms = rr_debug_time_flt<128, true>(ix, st, reps);
+            break;
+        case 320:
+            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
+            *out_ms = rr_debug_time_flt<192, true>(ix, st, reps);
             break;
         default: RR_REQUIRE(false, "unknown ablation %d", dbg);
     }

@@ -13,8 +13,10 @@ ix.dense_topk(np.random.default_rng(0).standard_normal((128, 384)).astype(np.flo
 names = {0: "full kernel", 1: "no epilogue", 2: "no B-fragment reads", 4: "no MFMA", 8: "no lane swaps / conversions",
          3: "no epilogue, no B reads", 7: "loads + swaps + conversions only", 15: "ring loads + maxima stores only",
          16: "no M-tile maxima stores", 31: "ring loads only", 32: "maxima stores non-temporal",
-         64: "bf16 plane: full kernel"}
-for v in [0, 0] + list(names)[1:] + [0]:
+         64: "bf16 plane: full kernel", 128: "bf16 plane: full kernel, ring loads from cache",
+         256: "bf16 plane: stamped", 320: "bf16 plane: stamped, ring loads from cache"}
+only = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else None
+for v in (only or [0, 0] + list(names)[1:] + [0]):
     ms = C.c_float()
     _lib.check(lib.rr_debug_scan_flt(ix.handle, v, 5, C.byref(ms)), "rr_debug_scan_flt")
     nbytes = n * (768 if v >= 64 else 1536)
