@@ -520,11 +520,317 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
     asm volatile("" :: "v"(junk));
     if ((DBG & 128) && prog && lane == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(prog) + wave * 4;
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(prog) + wave * 6;
         o[0] = dbg_kloop; o[1] = dbg_epi; o[2] = dbg_wait; o[3] = __builtin_amdgcn_s_memtime() - dbg_t0;
+        o[4] = 0; o[5] = 0;
     }
     if (h == 0) {
         // groups of this wave that hold no tile (a short last run): key 0 = "nothing here"
+        const int cg = (int)G.tiles_per_group;
+        for (int k = (int)((t1 - t0 + cg - 1) / cg); k < G.gpw; ++k)
+#pragma unroll
+            for (int t = 0; t < NQ2; ++t) smax[(wave * G.gpw + k) * QN + 32 * t + c] = 0u;
+#pragma unroll
+        for (int t = 0; t < NQ2; ++t) {
+            if (!my_dummy || ((pend_keep >> t) & 1u)) reinterpret_cast<uint32_t*>(gmax)[(m1 - 1) * QN + 32 * t + c] = pend[t];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the filter scan over a bf16 stream: 16x16x32 tiles
+// The scan of a bf16 matrix / of the bf16 filter plane (rr_scan_flt above stays the scan of fp32 rows).  Same stream,
+// same tile words, same bound; what differs is the matrix-core tiling.  In-kernel stamps on rr_scan_flt<4, bf16> showed
+// the K-loop, not HBM, pacing the two-set launch: a wave alone on its SIMD needed 45 cycles per 32-cycle MFMA, two
+// waves together no less -- the four v_permlane16_swap per 64 bytes of a row (the 32x32x16 A operand wants lane (row c,
+// k half h), the coalesced loads deliver (row l & 15, 16-byte piece l >> 4)) sit on the vector issue between the MFMAs.
+// v_mfma_f32_16x16x32_bf16 takes its A operand exactly as the loads deliver it (16 rows x 32 dims: lane l = row l & 15,
+// dims 8 (l >> 4) .. + 7), so a ring register IS an operand: no lane swaps, no staging registers.  Per 32-dim K-step
+// and wave: 2 NQ2 B fragments (16 queries each, one conflict-free 1 KiB ds_read_b128: the planes sit fragment-major
+// in LDS) x 2 row halves = 4 NQ2 MFMAs of 16 cycles -- the same matrix time and LDS traffic as before.
+//   C layout (lane l): query l & 15 of the fragment, rows 4 (l >> 4) + i of the 16-row half.  The maxima of the four
+// 8-row M-tiles come out of one v_permlane16_swap + one maximum per (row half, fragment pair), in the arrangement the
+// code stage wants (lanes < 32: M-tiles 0 / 2, lanes >= 32: M-tiles 1 / 3 of query 32 j + (l & 31)).
+//   Ring: 24 registers = one 32-row M-tile; the two registers of a K-step are its two A operands.  Two K-steps = one
+// 128-byte line of each row are re-loaded as soon as the second K-step's MFMAs are issued and waited for ten K-steps
+// later with a counted wait (the other five groups' 20 loads, and the NQ2 tile-word stores unless they fall inside
+// the group's own K-steps, are younger): a group has most of an M-tile of time to arrive, and no burst of twelve
+// loads holds the wave's issue while the matrix pipe idles.
+template <int NQ2, int DBG = 0, bool DUAL = false>
+__global__ __launch_bounds__(512, 2) void rr_scan_flt16(
+    const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [32*NQ2][48] units, NATURAL k order
+    float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq,
+    const float* __restrict__ sigma, uint32_t* __restrict__ dummy, int nq_b, int64_t gmax_set_stride,
+    uint32_t* __restrict__ prog, uint32_t seq, int tune) {
+    constexpr int THREADS = 512;
+    constexpr int QN = 32 * NQ2;
+    constexpr int NF = 2 * NQ2;                       // 16-query B fragments per K-step
+    constexpr int KS = 12;                            // 32-dim K-steps per row
+    constexpr int STORE_KS = 4;                       // the K-step whose first NQ2 slots carry the previous M-tile's words
+    __shared__ u32x4 qs[QN * RR_X3_UNITS];            // [K-step][fragment][k quarter][query of the fragment]: a fragment = 1 KiB, lane l reads unit l
+    __shared__ float sg[QN];
+    __shared__ int kdone[THREADS / 64];               // see `paired` in rr_scan_flt
+    __shared__ int simd_of[THREADS / 64];
+    int wg = blockIdx.x;
+    int set = 0;
+    if (DUAL) {                                       // workgroups b and b + 8 (same XCD): sets 0 and 1 of the same rows
+        set = (wg >> 3) & 1;
+        wg = ((wg >> 4) << 3) | (wg & 7);
+        plane += (size_t)set * (RR_FLT_MAXQ * RR_X3_UNITS);
+        eps += set * RR_FLT_MAXQ;
+        if (sigma) sigma += set * RR_FLT_MAXQ;
+        gmax += set * gmax_set_stride;
+        smax += (size_t)set * RR_FLT_MAXQ * RR_MAX_SCAN_WAVES;
+        nq = set ? nq_b : nq;
+    }
+    const int tid = threadIdx.x;
+    const uint64_t dbg_entry = (DBG & 128) ? __builtin_amdgcn_s_memrealtime() : 0;      // (100 MHz)
+    if (tid < THREADS / 64) kdone[tid] = 0;
+    if ((tid & 63) == 0) simd_of[tid >> 6] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
+    for (int i = tid; i < QN * RR_X3_UNITS; i += THREADS) {
+        const int q = i / RR_X3_UNITS, unit = i % RR_X3_UNITS;          // unit = 4 * K-step + k quarter
+        qs[(((unit >> 2) * NF + (q >> 4)) * 4 + (unit & 3)) * 16 + (q & 15)] = plane[i];
+    }
+    for (int i = tid; i < QN; i += THREADS) sg[i] = sigma ? sigma[i] : -INFINITY;
+    __syncthreads();
+
+    const int lane = tid & 63;
+    const int c = lane & 31, h = lane >> 5;           // tile words: query 32 j + c; M-tiles h and 2 + h
+    const int64_t wave = (int64_t)wg * (THREADS / 64) + (tid >> 6);
+    const int wid = tid >> 6, pw = wid ^ 4;           // this wave and the one on the same SIMD
+    if (wave >= G.n_waves) {
+        if (lane == 0) __hip_atomic_store(&kdone[wid], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+    bool paired = (tune & 8) && simd_of[wid] == simd_of[pw];
+    const int seat = wid >= 4 ? 1 : 0;
+    const int64_t t0 = wave * G.tiles_per_wave;
+    const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
+    const int64_t m0 = t0 * 2, m1 = t1 * 2;           // 32-row M-tiles of this wave
+    if ((DBG & 128) && (tune & 32) && wid >= 4) {     // timing only (stamped harness kernels): one wave per SIMD
+        if (lane == 0) __hip_atomic_store(&kdone[wid], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+    }
+
+    const int lrow = lane & 15, lpc = lane >> 4;      // load = operand order: row of the 16-row half, 16-B piece (k quarter)
+    const u32x4* px;
+    const u32x4* py;
+    auto seg_ptrs = [&](int64_t seg) {                // M-tile m0 + seg (past the end: redundant re-loads, never used)
+        int64_t mt = m0 + seg;
+        mt = mt < m1 ? mt : m1 - 1;
+        if (DBG & 64) mt = m0 + (mt & 1);             // timing only: every wave re-reads its first two M-tiles (cache hits)
+        int64_t rx = mt * 32 + lrow, ry = rx + 16;
+        rx = rx < G.n_rows ? rx : G.n_rows - 1;
+        ry = ry < G.n_rows ? ry : G.n_rows - 1;
+        px = mat + rx * RR_X3_UNITS + lpc;
+        py = mat + ry * RR_X3_UNITS + lpc;
+    };
+    u32x4 a[24];                                      // a[2 k] / a[2 k + 1]: rows 0-15 / 16-31, dims 32 k .. 32 k + 31
+    seg_ptrs(0);
+#pragma unroll
+    for (int j = 0; j < 24; ++j) RR_FLT_LOAD(a[j], j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    float gm[NQ2];                                    // running maximum of the current group (sub-run of tiles)
+    uint32_t pend[NQ2];                               // packed maxima of the 32-row tile just finished, stored one tile late
+    uint32_t pend_keep = 0xFFFFFFFFu;                 // bit j: the pending word of group j is wanted (wave-uniform), see rr_scan_flt
+    uint32_t junk = 0u;                               // destination of the loads that stand in for skipped stores
+    uint32_t* const my_dummy = dummy ? dummy + ((size_t)set * G.n_waves + wave) * QN : nullptr;
+    uint32_t* const my_prog = DUAL && prog ? prog + (size_t)set * G.n_waves + wave : nullptr;
+    const uint32_t* partner_prog = nullptr;
+    bool coupled = false;
+    if (DUAL && prog) {
+        const uint64_t pa = reinterpret_cast<uint64_t>(prog + (size_t)(set ^ 1) * G.n_waves + wave);
+        const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)pa), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
+        partner_prog = reinterpret_cast<const uint32_t*>(((uint64_t)hi32 << 32) | lo32);
+        coupled = true;
+    }
+    const uint32_t code_shift = 16u + 4u * (uint32_t)h;
+    const float step = rr_flt_gap_step(eps, nq);
+    const float inv_step = step > 0.f ? 0.9999f / step : 0.f;
+#pragma unroll
+    for (int t = 0; t < NQ2; ++t) {
+        gm[t] = -INFINITY;
+        pend[t] = 0x0000FF80u;                        // -inf, gaps 0
+    }
+    auto read_q = [&](int ks, int f) { return __builtin_bit_cast(bf16x8, qs[(ks * NF + f) * 64 + lane]); };
+    bf16x8 qf[NF];                                    // B fragments of the K-step at hand; each re-loaded in place for the next
+#pragma unroll
+    for (int f = 0; f < NF; ++f) qf[f] = read_q(0, f);
+
+    uint64_t dbg_turn = 0, ts_end = 0, dbg_kloop = 0, dbg_epi = 0;
+    const uint64_t dbg_t0 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t dbg_r0 = (DBG & 128) ? __builtin_amdgcn_s_memrealtime() : 0;
+#pragma unroll 1
+    for (int64_t mt = m0; mt < m1; ++mt) {
+        // The MFMAs are spelled out (accumulating in place, the first K-step with a literal zero C): left to the
+        // register allocator the unrolled chain took a fresh destination per MFMA, 256 registers and 49-86 spills,
+        // whose reloads (vmcnt(0)) sat in the K-loop.  The compiler still sees every operand (it places the lgkmcnt
+        // waits for the B fragments); what it cannot see is the MFMA -> VALU distance: see the s_nop behind the K-loop.
+        f32x4 acc[2][NF];
+        if (paired) {
+            const int need = (int)(mt - m0) + seat;
+            int spins = 0;
+            while (__hip_atomic_load(&kdone[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+                if (++spins > 200000) {        // (a safety net, never seen: ~20 ms)
+                    paired = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        uint64_t ts0 = 0;
+        if (DBG & 128) {
+            ts0 = __builtin_amdgcn_s_memtime();
+            if (mt > m0) dbg_turn += ts0 - ts_end;
+        }
+        if (tune & 16) __builtin_amdgcn_s_setprio(1);
+        seg_ptrs(mt - m0 + 1);                        // this M-tile's re-loads fill the ring for the next
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks % 2 == 0 && !(DBG & 4)) {
+                // the group (K-steps ks, ks + 1) was re-loaded ten K-steps ago; issued since: the other five groups (20
+                // loads) and -- unless they sit in this group's own K-steps -- one M-tile's NQ2 tile-word stores
+                if (ks / 2 == STORE_KS / 2 || (DBG & 16)) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(20 + NQ2) : "memory");
+                asm volatile("" : "+v"(a[2 * ks]), "+v"(a[2 * ks + 1]), "+v"(a[2 * ks + 2]), "+v"(a[2 * ks + 3]));
+            }
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, a[2 * ks]), a1 = __builtin_bit_cast(bf16x8, a[2 * ks + 1]);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                if (ks == 0) {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[0][f]) : "v"(a0), "v"(qf[f]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[1][f]) : "v"(a1), "v"(qf[f]));
+                } else {
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[0][f]) : "v"(a0), "v"(qf[f]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[1][f]) : "v"(a1), "v"(qf[f]));
+                }
+                if (!(DBG & 2)) qf[f] = read_q((ks + 1) % KS, f);     // in place: this fragment's turn comes again 2 NF MFMAs on
+                if (ks % 2 == 1 && f == NF - 1 && !(DBG & 4)) {
+                    // the MFMAs of the group's second K-step are issued: its four registers take the same 128 bytes of
+                    // the next M-tile's rows (the two halves of a line back to back)
+                    RR_FLT_LOAD(a[2 * ks - 2], 2 * ks - 2);
+                    RR_FLT_LOAD(a[2 * ks], 2 * ks);
+                    RR_FLT_LOAD(a[2 * ks - 1], 2 * ks - 1);
+                    RR_FLT_LOAD(a[2 * ks + 1], 2 * ks + 1);
+                }
+                if (ks == STORE_KS && f < NQ2 && !(DBG & (16 | 4))) {
+                    // the previous M-tile's words: NQ2 vector-memory operations, always (the ring waits count them);
+                    // first M-tile of the wave: nothing pending, the stores go to its own slot
+                    const int64_t mprev = mt > m0 ? mt - 1 : mt;
+                    if (DUAL && f == 0 && my_prog) {
+                        // ONE store instruction: group 0's tile words from the h == 0 lanes (if wanted) and this
+                        // wave's progress word from lane 32
+                        const bool want = !my_dummy || (pend_keep & 1u);
+                        if ((h == 0 && want) || lane == 32) {
+                            uint32_t* dst = lane == 32 ? my_prog : reinterpret_cast<uint32_t*>(gmax) + mprev * QN + c;
+                            const int64_t in_run = mt - m0 + 1;
+                            *dst = lane == 32 ? seq + (uint32_t)(in_run < 65535 ? in_run : 65535) : pend[0];
+                        }
+                    } else if (my_dummy && !((pend_keep >> f) & 1u)) {
+                        // skipped line: a load of this wave's own line stands in (see rr_scan_flt)
+                        asm volatile("global_load_dword %0, %1, off" : "+v"(junk) : "v"(my_dummy + lane) : "memory");
+                    } else if (h == 0) {
+                        reinterpret_cast<uint32_t*>(gmax)[mprev * QN + 32 * f + c] = pend[f];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the last MFMAs' results are read by vector instructions below: the wait states the compiler would count for
+        // its own MFMAs (at most 18 for any XDL write -> VALU read on gfx950; these are 4-pass)
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        if (tune & 16) __builtin_amdgcn_s_setprio(0);
+        if (lane == 0) __hip_atomic_store(&kdone[wid], (int)(mt - m0) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint64_t ts1 = 0;
+        if (DBG & 128) {
+            ts1 = __builtin_amdgcn_s_memtime();
+            dbg_kloop += ts1 - ts0;
+        }
+        // lane l, accumulator (r, f), register i: row 16 r + 4 (l >> 4) + i of the M-tile, query 16 f + (l & 15)
+        if (mt * 32 + 32 > G.n_rows) {                // the matrix's last, short M-tile: rows past the end (and NaNs) -> -inf
+            const int64_t rbase = mt * 32 + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[r][f] = rr_x3_canon(acc[r][f], rbase + 16 * r, G.n_rows);
+        }
+        uint32_t keep_now = 0u;
+#pragma unroll
+        for (int t = 0; t < NQ2; ++t) {
+            // maxima of rows 4 (l >> 4) .. + 3 per (row half, fragment); v_permlane16_swap(x, y) leaves x = {x.row0, y.row0,
+            // x.row2, y.row2}, y = {x.row1, y.row1, x.row3, y.row3} (rows of 16 lanes), so max(x, y) of fragments 2 t and
+            // 2 t + 1 of row half r holds, for query 32 t + (l & 31), the 8-row M-tile 2 r in lanes < 32 and 2 r + 1 above
+            float uw[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const f32x4 va = acc[r][2 * t], vb = acc[r][2 * t + 1];
+                const float x = rr_vmax3(va.x, va.y, rr_vmax(va.z, va.w)), y = rr_vmax3(vb.x, vb.y, rr_vmax(vb.z, vb.w));
+                const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                uw[r] = rr_vmax(__uint_as_float(rs[0]), __uint_as_float(rs[1]));
+            }
+            const float u = uw[0], w = uw[1];         // M-tiles h and 2 + h
+            const float mh = rr_vmax(u, w);
+            const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
+            const float m32 = rr_vmax(__uint_as_float(rm[0]), __uint_as_float(rm[1]));      // the tile maximum, in both halves
+            gm[t] = rr_vmax(gm[t], m32);
+            const bool kept = __ballot(m32 >= sg[32 * t + c]) != 0ull;                      // (wave-uniform)
+            keep_now |= (kept ? 1u : 0u) << t;
+            if (my_dummy && !kept) continue;                                                 // its word is never stored: no codes
+            // the word: see rr_scan_flt (bf16 tile maximum rounded up + four 4-bit gap codes rounded down)
+            const uint32_t b = __float_as_uint(m32);
+            uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);
+            const float gu = (m32 - u) * inv_step, gw = (m32 - w) * inv_step;
+            uint32_t cu = rr_cvt_u32_sat(gu), cw = rr_cvt_u32_sat(gw);
+            cu = cu < 12u ? cu : 12u;
+            cw = cw < 12u ? cw : 12u;
+            cu += (gu >= 16.f ? 1u : 0u) + (gu >= 24.f ? 1u : 0u) + (gu >= 40.f ? 1u : 0u);
+            cw += (gw >= 16.f ? 1u : 0u) + (gw >= 24.f ? 1u : 0u) + (gw >= 40.f ? 1u : 0u);
+            const uint32_t mine = (cu | (cw << 8)) << code_shift;
+            const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+            word |= rc[0] | rc[1];
+            pend[t] = word;
+        }
+        pend_keep = keep_now;
+        {   // group k of the wave = tiles [t0 + k Cg, t0 + (k + 1) Cg) of its run; its maximum is stored at once
+            const int in_run = (int)((mt >> 1) - t0), cg = (int)G.tiles_per_group;
+            if ((mt & 1) == 1 && ((in_run + 1) % cg == 0 || mt == m1 - 1)) {
+                const int64_t group = wave * G.gpw + in_run / cg;
+#pragma unroll
+                for (int t = 0; t < NQ2; ++t) {
+                    if (h == 0) smax[group * QN + 32 * t + c] = rr_f2key(gm[t]);
+                    gm[t] = -INFINITY;
+                }
+            }
+        }
+        if (DBG & 128) {
+            ts_end = __builtin_amdgcn_s_memtime();
+            dbg_epi += ts_end - ts1;
+        }
+        if (DUAL && coupled) {                        // the wave of the other set with the same rows: stay within L2's reach (see rr_scan_flt)
+            const int64_t in_run = mt - m0 + 1;
+            const uint32_t mine = seq + (uint32_t)(in_run < 65535 ? in_run : 65535);
+            uint32_t theirs;
+            int spins = 0;
+            for (;;) {
+                asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(theirs) : "s"(partner_prog) : "memory");
+                if ((int32_t)(theirs - mine) >= 0) break;
+                if (++spins >= 64) {
+                    coupled = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+    }
+    if (lane == 0) __hip_atomic_store(&kdone[wid], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
+    asm volatile("" :: "v"(junk));
+    if ((DBG & 128) && prog && lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(prog) + wave * 6;
+        o[0] = dbg_kloop; o[1] = dbg_epi; o[2] = dbg_turn; o[3] = __builtin_amdgcn_s_memtime() - dbg_t0;
+        o[4] = __builtin_amdgcn_s_memrealtime() - dbg_r0; o[5] = dbg_r0 - dbg_entry;
+    }
+    if (h == 0) {
         const int cg = (int)G.tiles_per_group;
         for (int k = (int)((t1 - t0 + cg - 1) / cg); k < G.gpw; ++k)
 #pragma unroll
@@ -562,7 +868,7 @@ __global__ __launch_bounds__(512, 1) void rr_flt_sample(const u32x4* __restrict_
         const u32x4* p = mat + (tile * 32 + c) * 48;
         u32x4 a[24];
 #pragma unroll
-        for (int s = 0; s < 24; ++s) a[s] = p[4 * (s >> 1) + 2 * h + (s & 1)];
+        for (int s = 0; s < 24; ++s) a[s] = p[2 * s + h];            // dims 16 s + 8 h .. + 7: the planes are in memory order
         f32x16 acc[TQ];
 #pragma unroll
         for (int t = 0; t < TQ; ++t)
@@ -715,7 +1021,8 @@ template <int NQ2, bool A_BF16>
 static rr_scan_geom rr_flt_geom(rr_index* ix, bool dual = false) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     static int waves = 0;
-    if (!waves) waves = rr_resident_waves((const void*)rr_scan_flt<NQ2, A_BF16>, THREADS, ix->device);
+    if (!waves) waves = A_BF16 ? rr_resident_waves((const void*)rr_scan_flt16<NQ2>, 512, ix->device)
+                               : rr_resident_waves((const void*)rr_scan_flt<NQ2, false>, THREADS, ix->device);
     rr_scan_geom G = rr_make_geom(ix, dual ? waves / 8 : waves / 4);
     G.qs = 32 * NQ2;
     G.mm_pairs = 3;
@@ -783,7 +1090,7 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
     float* gmax = ix->d_gmax + set * rr_flt_mmax_set_stride(G);
     uint32_t* smax = ix->d_smax + set * rr_flt_smax_set_stride();
     hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, eps, bounds,
-                       SCAN_BF16 ? RR_X3_ORDER_WIDE_BF16 : RR_X3_ORDER_NATURAL);
+                       RR_X3_ORDER_NATURAL);         // (both scans take their A operands in memory order)
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     // Store prefilter (bf16 stream, >= 2M rows): a 1/64 tile sample gives every query sigma = its m-th largest sampled
     // tile maximum - 2.05 eps.  The m-th largest of a 1/stride sample sits near rank m * stride of all rows; m leaves the
@@ -818,9 +1125,14 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
     }
     const int slot = rr_scan_events_begin(ix, st);
     rr_scan_note(ix, 5, NQ2, nq, 1, SCAN_BF16 ? 2 : 4);
-    hipLaunchKernelGGL((rr_scan_flt<NQ2, SCAN_BF16>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
-                       reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy, 0, (int64_t)0,
-                       (uint32_t*)nullptr, 0u, rr_flt_tune());
+    if (SCAN_BF16)
+        hipLaunchKernelGGL((rr_scan_flt16<NQ2>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+                           reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy, 0, (int64_t)0,
+                           (uint32_t*)nullptr, 0u, rr_flt_tune());
+    else
+        hipLaunchKernelGGL((rr_scan_flt<NQ2, false>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+                           reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy, 0, (int64_t)0,
+                           (uint32_t*)nullptr, 0u, rr_flt_tune());
     rr_scan_events_end(ix, slot, st);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
@@ -887,7 +1199,7 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
             RR_HIP_TRY(hipMemsetAsync(ix->d_flt_prog, 0, sizeof(uint32_t) * 2 * RR_MAX_SCAN_WAVES, st));
         }
         ix->flt_seq = (ix->flt_seq + 1) & 0x7FFFu;
-        hipLaunchKernelGGL((rr_scan_flt<4, SCAN_BF16, 0, true>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+        hipLaunchKernelGGL((rr_scan_flt16<4, 0, true>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
                            reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, sg0, dummy,
                            nq_b, rr_flt_mmax_set_stride(G), no_couple ? (uint32_t*)nullptr : ix->d_flt_prog,
                            (uint32_t)(ix->flt_seq + 1) << 16, rr_flt_tune());
@@ -953,8 +1265,8 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     unsigned long long* d_stamps = nullptr;
     if (DBG & 128) {
-        if (hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 4 * RR_MAX_SCAN_WAVES) != hipSuccess) return -1.f;
-        hipMemset(d_stamps, 0, sizeof(unsigned long long) * 4 * RR_MAX_SCAN_WAVES);
+        if (hipMalloc((void**)&d_stamps, sizeof(unsigned long long) * 6 * RR_MAX_SCAN_WAVES) != hipSuccess) return -1.f;
+        hipMemset(d_stamps, 0, sizeof(unsigned long long) * 6 * RR_MAX_SCAN_WAVES);
     }
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -962,11 +1274,16 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     float total = 0.f;
     for (int r = 0; r < reps + 1; ++r) {
         hipEventRecord(e0, st);
-        hipLaunchKernelGGL((rr_scan_flt<4, PLANE, DBG>), grid, block, 0, st,
-                           reinterpret_cast<const u32x4*>(PLANE ? (const void*)ix->d_shadow : (const void*)ix->d_matrix), G,
-                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128,
-                           (const float*)nullptr, (uint32_t*)nullptr, 0, (int64_t)0, reinterpret_cast<uint32_t*>(d_stamps), 0u,
-                           rr_flt_tune());
+        if constexpr (PLANE)
+            hipLaunchKernelGGL((rr_scan_flt16<4, DBG>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
+                               reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128,
+                               (const float*)nullptr, (uint32_t*)nullptr, 0, (int64_t)0, reinterpret_cast<uint32_t*>(d_stamps), 0u,
+                               rr_flt_tune());
+        else
+            hipLaunchKernelGGL((rr_scan_flt<4, false, DBG>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
+                               reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128,
+                               (const float*)nullptr, (uint32_t*)nullptr, 0, (int64_t)0, reinterpret_cast<uint32_t*>(d_stamps), 0u,
+                               rr_flt_tune());
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
         float ms = 0.f;
@@ -976,16 +1293,21 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     if (DBG & 128) {        // per-wave shader cycles of the last launch: K-loops, epilogues, ring waits, whole scan
-        std::vector<unsigned long long> h((size_t)4 * G.n_waves);
+        std::vector<unsigned long long> h((size_t)6 * G.n_waves);
         hipMemcpy(h.data(), d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         hipFree(d_stamps);
-        double sum[4] = {0, 0, 0, 0};
-        for (int w = 0; w < G.n_waves; ++w)
-            for (int k = 0; k < 4; ++k) sum[k] += (double)h[(size_t)4 * w + k];
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        int live = 0;
+        for (int w = 0; w < G.n_waves; ++w) {
+            if (h[(size_t)6 * w + 3]) ++live;
+            for (int k = 0; k < 6; ++k) sum[k] += (double)h[(size_t)6 * w + k];
+        }
+        // (with RR_FLT_TUNE=32 only every other wave runs: the per-M-tile figures are then per TWO M-tiles of a running wave)
         const double tiles = (double)((G.n_rows + 31) / 32);
-        fprintf(stderr, "[flt stamps] per M-tile and wave, shader cycles: K-loop %.0f (of which ring waits %.0f), epilogue %.0f; "
-                        "whole scan per wave %.0f cycles, %d waves\n", sum[0] / tiles, sum[2] / tiles, sum[1] / tiles,
-                sum[3] / G.n_waves, G.n_waves);
+        fprintf(stderr, "[flt stamps] per M-tile and wave, shader cycles: K-loop %.0f, between epilogue and K-loop (or ring waits) %.0f, "
+                        "epilogue %.0f; tile loop per wave %.0f cycles = %.1f us (100 MHz clock), kernel entry to the loop %.1f us, "
+                        "%d waves wrote\n", sum[0] / tiles, sum[2] / tiles, sum[1] / tiles, sum[3] / (live ? live : 1),
+                sum[4] / (live ? live : 1) / 100.0, sum[5] / (live ? live : 1) / 100.0, live);
     }
     return total / reps;
 }
@@ -1028,6 +1350,20 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
         case 320:
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
             *out_ms = rr_debug_time_flt<192, true>(ix, st, reps);
+            break;
+        // 400 / 401 / 402 (16x16x32 kernel only; wrong results): stamped, cached, without the B-fragment reads / without the
+        // ring re-loads, waits and tile-word stores / without either = the bare MFMA chain + epilogue
+        case 400:
+            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
+            *out_ms = rr_debug_time_flt<192 | 2, true>(ix, st, reps);
+            break;
+        case 401:
+            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
+            *out_ms = rr_debug_time_flt<192 | 4, true>(ix, st, reps);
+            break;
+        case 402:
+            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
+            *out_ms = rr_debug_time_flt<192 | 6, true>(ix, st, reps);
             break;
         default: RR_REQUIRE(false, "unknown ablation %d", dbg);
     }

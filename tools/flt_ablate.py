@@ -14,7 +14,8 @@ names = {0: "full kernel", 1: "no epilogue", 2: "no B-fragment reads", 4: "no MF
          3: "no epilogue, no B reads", 7: "loads + swaps + conversions only", 15: "ring loads + maxima stores only",
          16: "no M-tile maxima stores", 31: "ring loads only", 32: "maxima stores non-temporal",
          64: "bf16 plane: full kernel", 128: "bf16 plane: full kernel, ring loads from cache",
-         256: "bf16 plane: stamped", 320: "bf16 plane: stamped, ring loads from cache"}
+         256: "bf16 plane: stamped", 320: "bf16 plane: stamped, ring loads from cache",
+         400: "stamped, cached, no B-fragment reads", 401: "stamped, cached, no ring re-loads / stores", 402: "stamped, cached: MFMA chain + epilogue only"}
 only = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else None
 for v in (only or [0, 0] + list(names)[1:] + [0]):
     ms = C.c_float()
