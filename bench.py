@@ -346,6 +346,27 @@ def main():
     if os.environ.get("RR_BENCH_DEBUG"):
         print("per-step ms:", np.round(per_step, 3).tolist(), file=sys.stderr, flush=True)
 
+    # the same filter scan with ONE query set per launch (128 queries per pass over the stream): the HBM-bound form of
+    # the kernel -- the two-set launch above reads the stream once for 256 queries and is paced by the matrix side
+    one_set = None
+    if args.batch > 128 and info["queries_per_launch"] > 128:
+        q128 = q_dev[0][:128].contiguous()
+        for _ in range(2):
+            sharded.s.dense_pool(q128, pool)
+        torch.cuda.synchronize()
+        _scan_stats(index)
+        for _ in range(10):
+            sharded.s.dense_pool(q128, pool)
+        torch.cuda.synchronize()
+        ms128, n128 = _scan_stats(index)
+        i128 = _scan_info(index)
+        b128 = n_local * DIM * i128["elem_bytes"]
+        gbs128 = b128 / (ms128 / max(n128, 1) * 1e-3) / 1e9
+        one_set = {"bound": "hbm", "achieved": round(gbs128, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(gbs128 / HBM_PEAK_GBS, 4), "kernel": i128["kernel"], "launches": int(n128),
+                   "avg_launch_ms": round(ms128 / max(n128, 1), 5), "bytes_per_launch": b128,
+                   "queries_per_launch": i128["queries_per_launch"]}
+
     # the HBM-bound end of the path: one query per matrix read (rr_scan_f32<6,1>), same shard
     q1 = q_dev[0][:1].contiguous()
     for _ in range(2):
@@ -417,6 +438,7 @@ def main():
             "roofline": roof,
             # the single-query scan on the same shard: the HBM-bound end of the same path
             "roofline_single_query": single,
+            **({"roofline_one_query_set": one_set} if one_set else {}),
         }
         if rerank_fn is not None:
             out["metric"] = f"queries/sec, hybrid + cross-encoder rerank top-{args.rerank_k} -> top-{args.k}"
@@ -450,6 +472,8 @@ def _scan_info(index):
     _lib.check(_lib.load().rr_index_last_scan_info(index.handle, out), "rr_index_last_scan_info")
     kid, variant, qpl, terms, ebytes = out[0], out[1], out[2], out[3], out[4]
     name = _KERNELS.get(kid, "unknown").replace("NQ2", str(variant)).replace("NQT", str(variant)).replace("NB", str(variant))
+    if kid == 5 and ebytes == 2:          # a bf16 stream is scanned on 16x16x32 tiles; variant 8 = one launch for two 128-query sets
+        name = "rr_scan_flt16<4, two query sets>" if variant == 8 else f"rr_scan_flt16<{variant}>"
     stream = "bf16 rows" if index.dtype == "bf16" else ("bf16 filter plane of the fp32 rows" if ebytes == 2 else "fp32 rows")
     return {"kernel": f"{name} over {stream}", "queries_per_launch": int(qpl), "mfma_terms": int(terms),
             "elem_bytes": int(ebytes) or (2 if index.dtype == "bf16" else 4)}

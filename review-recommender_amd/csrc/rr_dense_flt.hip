@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void rr_row_norm_max(const void* __restrict__ 
 }
 
 // ------------------------------------------------------------------ the filter scan
+// v_max_f32 / v_max3_f32 / v_cvt_u32_f32 spelled out: fmaxf() brings a canonicalising v_max x, x, x per operand with it
+// (three instructions per maximum); like fmaxf they return the other operand for a NaN.  The conversion saturates and
+// turns NaN into 0 (a C++ cast is undefined there).
 __device__ __forceinline__ float rr_vmax(float a, float b) {
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -131,11 +134,14 @@ __device__ __forceinline__ float rr_vmax3(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ uint32_t rr_cvt_u32_sat(float x) {       // saturating, NaN -> 0 (a C++ cast is undefined there)
+__device__ __forceinline__ uint32_t rr_cvt_u32_sat(float x) {
     uint32_t r;
     asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
+// rr_scan_flt below is the scan of FP32 rows (an fp32 index without its bf16 filter plane: RR_NO_SHADOW=1, or no room
+// for the plane); a bf16 stream -- the plane, or a bf16 matrix -- is scanned by rr_scan_flt16 further down and the
+// A_BF16 = true side of this template is no longer instantiated.
 // RR_FLT_THREADS(NQ2): workgroup size.  Four query tiles want 270 registers for a B-fragment lead of two
 // K-steps; RR_FLT_ONE_WAVE=1 builds that variant (one wave per SIMD, the whole register file, lead 2):
 // measured equal to two waves per SIMD with lead 1 (scan(128 q) / scan(32 q) = 1.14 either way), so off.
@@ -145,49 +151,20 @@ __device__ __forceinline__ uint32_t rr_cvt_u32_sat(float x) {       // saturatin
 #endif
 // DBG != 0: timing-only ablations (rr_debug_scan_flt, tools/flt_ablate.py; wrong results): bit 0 no epilogue
 // (accumulators kept alive), bit 1 no B-fragment reads, bit 2 no MFMAs, bit 3 no lane swaps / conversions, bit 4 no M-tile maxima stores.
-//
-// DUAL: ONE launch serves TWO query sets (2 x 128 queries) with one pass over the matrix out of HBM.  The grid is still
-// one workgroup per CU, but a workgroup belongs to a set (its LDS holds that set's planes) and the row runs are twice
-// as long: workgroups b and b + 8 -- consecutive workgroups of the SAME XCD under the round-robin dispatch -- walk the
-// same runs for set 0 and set 1.  Whichever of the two is ahead pulls a line into that XCD's L2 (or the die's Infinity
-// Cache); the other finds it there, gets its data sooner and catches up, so the pair stays within a burst of each
-// other and the matrix leaves HBM once for 256 queries.  Set 1's planes / eps / sigma sit RR_FLT_MAXQ entries behind
-// set 0's, its tile and group maxima at the set strides of rr_flt_scan_set.
-template <int NQ2, bool A_BF16, int DBG = 0, bool DUAL = false>
+template <int NQ2, bool A_BF16, int DBG = 0>
 __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 1 : 2)) void rr_scan_flt(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [32*NQ2][48] units
     float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq,
     const float* __restrict__ sigma,      // [32*NQ2] store prefilter (null: every tile word is stored), see rr_flt_sample
-    uint32_t* __restrict__ dummy,         // [n_waves][32*NQ2] lines that absorb the skipped stores
-    int nq_b = 0, int64_t gmax_set_stride = 0,        // DUAL: queries of set 1, words between the sets' tile maxima,
-    uint32_t* __restrict__ prog = nullptr, uint32_t seq = 0,     // [2][n_waves] progress words, launch number << 16
-    int tune = 0) {                       // experiment switches (RR_FLT_TUNE): see rr_flt_tune()
+    uint32_t* __restrict__ dummy) {       // [n_waves][32*NQ2] lines that absorb the skipped stores
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
-    int wg = blockIdx.x;                               // workgroup's place in the row partition
-    int set = 0;
-    if (DUAL) {
-        set = (wg >> 3) & 1;
-        wg = ((wg >> 4) << 3) | (wg & 7);
-        plane += (size_t)set * (RR_FLT_MAXQ * RR_X3_UNITS);
-        eps += set * RR_FLT_MAXQ;
-        if (sigma) sigma += set * RR_FLT_MAXQ;
-        gmax += set * gmax_set_stride;
-        smax += (size_t)set * RR_FLT_MAXQ * RR_MAX_SCAN_WAVES;
-        nq = set ? nq_b : nq;
-    }
     constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
     constexpr int SEGS = A_BF16 ? 1 : 2;              // ring segments (24 units per lane) per 32-row M-tile
     constexpr int STEPS = A_BF16 ? 24 : 12;           // K-steps (16 dims) per ring segment
     __shared__ u32x4 qs[QN * RR_FLT_QSTRIDE];
     __shared__ float sg[QN];
-    // The two waves of a SIMD take turns in the K-loop (see `paired` below): K-loops each wave has finished, and the
-    // SIMD each wave sits on (HW_REG_HW_ID bits 5:4)
-    __shared__ int kdone[THREADS / 64];
-    __shared__ int simd_of[THREADS / 64];
     const int tid = threadIdx.x;
-    if (tid < THREADS / 64) kdone[tid] = 0;
-    if ((tid & 63) == 0) simd_of[tid >> 6] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
     for (int i = tid; i < QN * RR_X3_UNITS; i += THREADS)
         qs[(i / RR_X3_UNITS) * RR_FLT_QSTRIDE + (i % RR_X3_UNITS)] = plane[i];
     for (int i = tid; i < QN; i += THREADS) sg[i] = sigma ? sigma[i] : -INFINITY;
@@ -196,27 +173,11 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     const int lane = tid & 63;
     const int c = lane & 31;                          // MFMA: A row / B and C column
     const int h = lane >> 5;                          //       k half (A, B); C rows 8g + 4h + i
-    const int64_t wave = (int64_t)wg * (THREADS / 64) + (tid >> 6);
-    const int wid = tid >> 6, pw = wid ^ (THREADS / 128);      // this wave and the one expected on the same SIMD
-    if (wave >= G.n_waves) {
-        if (lane == 0) kdone[wid] = 0x7FFFFFFF;                // nobody waits for a wave without rows
-        return;
-    }
-    // Two waves per SIMD left alone fall into step: both in the K-loop (sharing the matrix pipe), then both in the
-    // epilogue (sharing the vector issue, matrix pipe idle) -- measured with in-kernel stamps: K-loop 6.9 k cycles,
-    // epilogue 5.4 k per M-tile, of 3.1 k MFMA cycles each.  So they take turns: K-loop i of the second wave starts when
-    // K-loop i of the first is done, K-loop i + 1 of the first when K-loop i of the second is done; each epilogue then
-    // runs in the issue gaps of the other wave's MFMAs.  (A wave waits on the LDS counter of its partner; a partner on
-    // another SIMD -- not how workgroups are placed, but not a contract either -- or one that stops counting switches it off.)
-    bool paired = (tune & 8) && THREADS == 512 && simd_of[wid] == simd_of[pw];
-    const int seat = wid >= THREADS / 128 ? 1 : 0;
+    const int64_t wave = (int64_t)blockIdx.x * (THREADS / 64) + (tid >> 6);
+    if (wave >= G.n_waves) return;
     const int64_t t0 = wave * G.tiles_per_wave;
     const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
     const int64_t m0 = t0 * 2, m1 = t1 * 2;           // 32-row M-tiles of this wave
-    const bool second = (tid >> 6) >= THREADS / 128;  // the second wave of its SIMD (waves w and w + 4 share one)
-    if ((tune & 2) && second) {                       // start half an M-tile late: epilogue (VALU) against the other's K-loop (MFMA)
-        __builtin_amdgcn_s_sleep(100);               // 6400 cycles
-    }
 
     const int lrow = lane & 15, lpc = lane >> 4;      // load order: row of the 16-row half, 16-B piece
     const u32x4* px;
@@ -225,7 +186,6 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
         int64_t mt = m0 + seg / SEGS;
         const int p = (int)(seg % SEGS);
         mt = mt < m1 ? mt : m1 - 1;                   // (past the end: redundant re-loads, never used)
-        if (DBG & 64) mt = m0 + (mt & 1);             // timing only: every wave re-reads its first two M-tiles (cache hits)
         int64_t rx = mt * 32 + lrow, ry = rx + 16;
         rx = rx < G.n_rows ? rx : G.n_rows - 1;
         ry = ry < G.n_rows ? ry : G.n_rows - 1;
@@ -251,23 +211,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     // stores cost) drop with the lines skipped.
     uint32_t pend_keep = 0xFFFFFFFFu;                 // bit j: the pending word of group j is wanted (wave-uniform)
     uint32_t junk = 0u;                               // destination of the loads that stand in for skipped stores
-    uint32_t* const my_dummy = dummy ? dummy + ((size_t)set * G.n_waves + wave) * QN : nullptr;
-    // DUAL: the pair (this wave, the wave of the other set with the same run) only shares its reads while the two stay
-    // within the L2's retention (~ a tile) of each other; once they drift further both miss and nothing pulls them
-    // back.  So each wave publishes the M-tile it is in (lane 32 of group 0's tile-word store instruction: no extra
-    // vector-memory operation for the counted ring waits) and, at the end of that M-tile, the one that is ahead
-    // waits -- a bounded number of scalar polls; a wave whose partner never shows up stops looking -- until the
-    // other has reached the same M-tile.
-    uint32_t* const my_prog = DUAL && prog ? prog + (size_t)set * G.n_waves + wave : nullptr;
-    const uint32_t* partner_prog = nullptr;
-    bool coupled = false;
-    if (DUAL && prog) {
-        const uint64_t pa = reinterpret_cast<uint64_t>(prog + (size_t)(set ^ 1) * G.n_waves + wave);
-        const uint32_t lo32 = __builtin_amdgcn_readfirstlane((uint32_t)pa), hi32 = __builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32));
-        partner_prog = reinterpret_cast<const uint32_t*>(((uint64_t)hi32 << 32) | lo32);
-        coupled = true;
-    }
-    const uint32_t code_shift = 16u + 4u * (uint32_t)h;     // this k half encodes M-tiles h and 2 + h (bits 16 + 4 g)
+    uint32_t* const my_dummy = dummy ? dummy + (size_t)wave * QN : nullptr;
     const float step = rr_flt_gap_step(eps, nq);      // resolution of the 8-row gaps (half the smallest eps of the launch)
     const float inv_step = step > 0.f ? 0.9999f / step : 0.f;    // (0.9999: the decoded bound never rounds below the maximum)
 #pragma unroll
@@ -310,33 +254,13 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
         }
     }
 
-    uint64_t dbg_kloop = 0, dbg_epi = 0, dbg_wait = 0;      // DBG & 128: shader cycles of this wave in the K-loops (ring waits
-    const uint64_t dbg_t0 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;   // included), in the epilogues, in the ring waits
 #pragma unroll 1
     for (int64_t mt = m0; mt < m1; ++mt) {
-        uint64_t ts0 = 0;
-        if (DBG & 128) ts0 = __builtin_amdgcn_s_memtime();
         f32x16 acc[NQ2];
 #pragma unroll
         for (int t = 0; t < NQ2; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-        if (paired) {
-            const int need = (int)(mt - m0) + seat;
-            int spins = 0;
-            while (__hip_atomic_load(&kdone[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-                if (++spins > 200000) {        // (a safety net, never seen: ~20 ms)
-                    paired = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        if (tune & 4) {                    // K-loop: the first wave of the SIMD owns the matrix pipe, the second takes what is left
-            if (second) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(2);
-        }
-        if (tune & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int p = 0; p < SEGS; ++p) {
             seg_ptrs((mt - m0) * SEGS + p + 1);           // the bursts of this segment refill the ring for the next
@@ -344,7 +268,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
             for (int s = 0; s < STEPS; ++s) {
                 const int cb = (p * STEPS + s) & 1;
                 const int s2 = (s + 1) % STEPS;                           // the K-step being prepared
-                constexpr int LEAD = (NQ2 >= 4 && THREADS == 512) ? 1 : 2;   // K-steps of B-fragment prefetch (2 measured no faster at 4 tiles x 2 waves/SIMD)   // K-steps of B-fragment prefetch (4 tiles x 2 waves/SIMD: no registers for 2)
+                constexpr int LEAD = (NQ2 >= 4 && THREADS == 512) ? 1 : 2;   // K-steps of B-fragment prefetch (4 tiles x 2 waves/SIMD: no registers for 2)
                 const int kk3 = A_BF16 ? (s + LEAD) % 24 : (12 * p + s + LEAD) % 24;   // K-step of the row LEAD steps ahead
                 const bool swap = A_BF16 ? (s2 % 2 == 0) : true;          // it starts a new pair of the ring
                 const int np = A_BF16 ? s2 / 2 : s2;
@@ -354,11 +278,8 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                     // ring waits and deferred maxima stores exactly as in rr_scan_x3w
                     // (younger than what the wait needs: the other half's burst, and for the segment's second wait
                     //  the NQ2 maxima stores issued during the K-step after the first burst, see below)
-                    uint64_t tw0 = 0;
-                    if (DBG & 128) tw0 = __builtin_amdgcn_s_memtime();
                     if (p == 0 && (np == 0 || s > STORE_STEP) && !(DBG & 16)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + NQ2) : "memory");
                     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    if (DBG & 128) dbg_wait += __builtin_amdgcn_s_memtime() - tw0;
 #pragma unroll
                     for (int j = 0; j < 12; ++j) asm volatile("" : "+v"(a[(np / 6) * 12 + j]));
                 }
@@ -392,16 +313,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                     // into a saturated read stream.
                     if (p == 0 && s == STORE_STEP && !(DBG & 16)) {
                         const int64_t mprev = mt > m0 ? mt - 1 : mt;
-                        if (DUAL && j == 0 && my_prog) {
-                            // ONE store instruction: group 0's tile words from the h == 0 lanes (if wanted) and this
-                            // wave's progress word from lane 32
-                            const bool want = !my_dummy || (pend_keep & 1u);
-                            if ((h == 0 && want) || lane == 32) {
-                                uint32_t* dst = lane == 32 ? my_prog : reinterpret_cast<uint32_t*>(gmax) + mprev * QN + c;
-                                const int64_t in_run = mt - m0 + 1;
-                                *dst = lane == 32 ? seq + (uint32_t)(in_run < 65535 ? in_run : 65535) : pend[0];
-                            }
-                        } else if (my_dummy && !((pend_keep >> j) & 1u)) {
+                        if (my_dummy && !((pend_keep >> j) & 1u)) {
                             // skipped line: a LOAD of this wave's own (cache-resident) line keeps the count of vector-memory
                             // operations in flight that the ring waits assume; a store to such a line still went out to
                             // HBM (PMC WRITE_SIZE unchanged at 165 MB per launch: full-line writes are streamed through)
@@ -425,65 +337,45 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                 for (int e = 0; e < 16; ++e) asm volatile("" :: "v"(acc[t][e]));
             continue;
         }
-        if (tune & (4 | 16)) __builtin_amdgcn_s_setprio(0);
-        if (THREADS == 512 && lane == 0) __hip_atomic_store(&kdone[wid], (int)(mt - m0) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        uint64_t ts1 = 0;
-        if (DBG & 128) {
-            ts1 = __builtin_amdgcn_s_memtime();
-            dbg_kloop += ts1 - ts0;
-        }
         // lane (c, h), register 4g + i: row 8g + 4h + i of the M-tile, query 32t + c
         const int64_t rbase = mt * 32 + 4 * h;
-        if (mt * 32 + 32 > G.n_rows) {                // the matrix's last, short M-tile: rows past the end (and NaNs) -> -inf
-#pragma unroll
-            for (int t = 0; t < NQ2; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-                    v = rr_x3_canon(v, rbase + 8 * g, G.n_rows);
-                    acc[t][4 * g] = v.x; acc[t][4 * g + 1] = v.y; acc[t][4 * g + 2] = v.z; acc[t][4 * g + 3] = v.w;
-                }
-        }
+        const bool full = mt * 32 + 32 <= G.n_rows;
         uint32_t keep_now = 0u;
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
-            // (v_max_f32 / v_max3_f32 spelled out: fmaxf() brings a canonicalising v_max x, x, x per operand with it --
-            //  three instructions per maximum; like fmaxf they return the other operand for a NaN)
-            // lane-local maxima of the four 8-row M-tiles' rows in this k half (registers 4g .. 4g + 3)
-            float p8[4];
+            // maxima of the four 8-row M-tiles (rows 8g .. 8g + 7 = registers 4g .. 4g + 3 of both k halves)
+            float m8[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) p8[g] = rr_vmax3(acc[t][4 * g], acc[t][4 * g + 1], rr_vmax(acc[t][4 * g + 2], acc[t][4 * g + 3]));
-            // the other k half's rows sit in lane l ^ 32.  v_permlane32_swap(x, y) leaves x = {x.lo, y.lo}, y = {x.hi, y.hi},
-            // so max(x, y) of (p8[0], p8[1]) is the whole M-tile 0 in the lower 32 lanes and M-tile 1 in the upper 32:
-            // lane half h ends up with the maxima of M-tiles h (u) and 2 + h (w) of query column c -- two swaps, not four
-            const auto r01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p8[0]), __float_as_uint(p8[1]), false, false);
-            const auto r23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(p8[2]), __float_as_uint(p8[3]), false, false);
-            const float u = rr_vmax(__uint_as_float(r01[0]), __uint_as_float(r01[1]));
-            const float w = rr_vmax(__uint_as_float(r23[0]), __uint_as_float(r23[1]));
-            const float mh = rr_vmax(u, w);
-            const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
-            const float m32 = rr_vmax(__uint_as_float(rm[0]), __uint_as_float(rm[1]));      // the tile maximum, in both halves
-            gm[t] = rr_vmax(gm[t], m32);
-            const bool kept = __ballot(m32 >= sg[32 * t + c]) != 0ull;                      // (wave-uniform)
-            keep_now |= (kept ? 1u : 0u) << t;
-            if (my_dummy && !kept) continue;                                                 // its word is never stored: no codes
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                if (!full) v = rr_x3_canon(v, rbase + 8 * g, G.n_rows);            // (fmaxf drops a NaN by itself)
+                m8[g] = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+            }
+            // the other k half's rows (lane l ^ 32)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m8[g]), __float_as_uint(m8[g]), false, false);
+                m8[g] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+            }
             // 4 bytes per (32-row tile, query): the tile maximum as bf16 ROUNDED UP + for each 8-row M-tile how far
             // below it its own maximum sits, in units of `step`, ROUNDED DOWN to a 4-bit code (0..12 steps, then
             // >= 16, 24, 40).  The filter only asks "can this M-tile hold a score >= threshold": the decoded value
             // max_up - steps(code) * step is an upper bound of the M-tile's maximum.
+            const float m32 = fmaxf(fmaxf(m8[0], m8[1]), fmaxf(m8[2], m8[3]));
+            gm[t] = fmaxf(gm[t], m32);
+            keep_now |= (__ballot(m32 >= sg[32 * t + c]) != 0ull ? 1u : 0u) << t;
             const uint32_t b = __float_as_uint(m32);
             uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);           // toward +inf; +-inf stay
-            // codes of this half's two M-tiles: min(floor(gap), 12) + [gap >= 16] + [gap >= 24] + [gap >= 40]
-            // (v_cvt_u32_f32 saturates and turns NaN -- inf - inf -- into 0; the comparisons are false for NaN: code 0)
-            const float gu = (m32 - u) * inv_step, gw = (m32 - w) * inv_step;        // >= 0, in steps
-            uint32_t cu = rr_cvt_u32_sat(gu), cw = rr_cvt_u32_sat(gw);
-            cu = cu < 12u ? cu : 12u;
-            cw = cw < 12u ? cw : 12u;
-            cu += (gu >= 16.f ? 1u : 0u) + (gu >= 24.f ? 1u : 0u) + (gu >= 40.f ? 1u : 0u);
-            cw += (gw >= 16.f ? 1u : 0u) + (gw >= 24.f ? 1u : 0u) + (gw >= 40.f ? 1u : 0u);
-            const uint32_t mine = (cu | (cw << 8)) << code_shift;                    // M-tile g's code at bit 16 + 4 g
-            const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
-            word |= rc[0] | rc[1];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float gap = (m32 - m8[g]) * inv_step;                          // >= 0, in steps; inf - inf = NaN -> code 0
+                uint32_t code = (uint32_t)fminf(gap, 12.f);                          // 0 .. 12 steps exactly (rounded down), then
+                code = gap >= 16.f ? 13u : code;                                     // "at least 16 | 24 | 40 steps" (RR_FLT_GAP_STEPS):
+                code = gap >= 24.f ? 14u : code;                                     // an ordinary M-tile next to a top row sits ~30 eps
+                code = gap >= 40.f ? 15u : code;                                     // below it and must not be opened with it
+                code = gap == gap ? code : 0u;
+                word |= code << (16 + 4 * g);
+            }
             pend[t] = word;
         }
         pend_keep = keep_now;
@@ -499,31 +391,9 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                 }
             }
         }
-        if (DBG & 128) dbg_epi += __builtin_amdgcn_s_memtime() - ts1;
-        if (DUAL && coupled) {
-            const int64_t in_run = mt - m0 + 1;
-            const uint32_t mine = seq + (uint32_t)(in_run < 65535 ? in_run : 65535);
-            uint32_t theirs;
-            int spins = 0;
-            for (;;) {
-                asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(theirs) : "s"(partner_prog) : "memory");
-                if ((int32_t)(theirs - mine) >= 0) break;
-                if (++spins >= 64) {            // ~40 us: the partner is not resident (or not on this XCD): go alone
-                    coupled = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
     }
-    if (THREADS == 512 && lane == 0) __hip_atomic_store(&kdone[wid], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
     asm volatile("" :: "v"(junk));
-    if ((DBG & 128) && prog && lane == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(prog) + wave * 6;
-        o[0] = dbg_kloop; o[1] = dbg_epi; o[2] = dbg_wait; o[3] = __builtin_amdgcn_s_memtime() - dbg_t0;
-        o[4] = 0; o[5] = 0;
-    }
     if (h == 0) {
         // groups of this wave that hold no tile (a short last run): key 0 = "nothing here"
         const int cg = (int)G.tiles_per_group;
@@ -568,8 +438,6 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
     constexpr int STORE_KS = 4;                       // the K-step whose first NQ2 slots carry the previous M-tile's words
     __shared__ u32x4 qs[QN * RR_X3_UNITS];            // [K-step][fragment][k quarter][query of the fragment]: a fragment = 1 KiB, lane l reads unit l
     __shared__ float sg[QN];
-    __shared__ int kdone[THREADS / 64];               // see `paired` in rr_scan_flt
-    __shared__ int simd_of[THREADS / 64];
     int wg = blockIdx.x;
     int set = 0;
     if (DUAL) {                                       // workgroups b and b + 8 (same XCD): sets 0 and 1 of the same rows
@@ -584,8 +452,6 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
     }
     const int tid = threadIdx.x;
     const uint64_t dbg_entry = (DBG & 128) ? __builtin_amdgcn_s_memrealtime() : 0;      // (100 MHz)
-    if (tid < THREADS / 64) kdone[tid] = 0;
-    if ((tid & 63) == 0) simd_of[tid >> 6] = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
     for (int i = tid; i < QN * RR_X3_UNITS; i += THREADS) {
         const int q = i / RR_X3_UNITS, unit = i % RR_X3_UNITS;          // unit = 4 * K-step + k quarter
         qs[(((unit >> 2) * NF + (q >> 4)) * 4 + (unit & 3)) * 16 + (q & 15)] = plane[i];
@@ -596,20 +462,11 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
     const int lane = tid & 63;
     const int c = lane & 31, h = lane >> 5;           // tile words: query 32 j + c; M-tiles h and 2 + h
     const int64_t wave = (int64_t)wg * (THREADS / 64) + (tid >> 6);
-    const int wid = tid >> 6, pw = wid ^ 4;           // this wave and the one on the same SIMD
-    if (wave >= G.n_waves) {
-        if (lane == 0) __hip_atomic_store(&kdone[wid], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return;
-    }
-    bool paired = (tune & 8) && simd_of[wid] == simd_of[pw];
-    const int seat = wid >= 4 ? 1 : 0;
+    if (wave >= G.n_waves) return;
     const int64_t t0 = wave * G.tiles_per_wave;
     const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
     const int64_t m0 = t0 * 2, m1 = t1 * 2;           // 32-row M-tiles of this wave
-    if ((DBG & 128) && (tune & 32) && wid >= 4) {     // timing only (stamped harness kernels): one wave per SIMD
-        if (lane == 0) __hip_atomic_store(&kdone[wid], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return;
-    }
+    if ((DBG & 128) && (tune & 32) && (tid >> 6) >= 4) return;     // timing only (stamped harness kernels): one wave per SIMD
 
     const int lrow = lane & 15, lpc = lane >> 4;      // load = operand order: row of the 16-row half, 16-B piece (k quarter)
     const u32x4* px;
@@ -667,23 +524,11 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
         // whose reloads (vmcnt(0)) sat in the K-loop.  The compiler still sees every operand (it places the lgkmcnt
         // waits for the B fragments); what it cannot see is the MFMA -> VALU distance: see the s_nop behind the K-loop.
         f32x4 acc[2][NF];
-        if (paired) {
-            const int need = (int)(mt - m0) + seat;
-            int spins = 0;
-            while (__hip_atomic_load(&kdone[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-                if (++spins > 200000) {        // (a safety net, never seen: ~20 ms)
-                    paired = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
         uint64_t ts0 = 0;
         if (DBG & 128) {
             ts0 = __builtin_amdgcn_s_memtime();
             if (mt > m0) dbg_turn += ts0 - ts_end;
         }
-        if (tune & 16) __builtin_amdgcn_s_setprio(1);
         seg_ptrs(mt - m0 + 1);                        // this M-tile's re-loads fill the ring for the next
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -739,8 +584,6 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
         // the last MFMAs' results are read by vector instructions below: the wait states the compiler would count for
         // its own MFMAs (at most 18 for any XDL write -> VALU read on gfx950; these are 4-pass)
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
-        if (tune & 16) __builtin_amdgcn_s_setprio(0);
-        if (lane == 0) __hip_atomic_store(&kdone[wid], (int)(mt - m0) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         uint64_t ts1 = 0;
         if (DBG & 128) {
             ts1 = __builtin_amdgcn_s_memtime();
@@ -822,7 +665,6 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
             }
         }
     }
-    if (lane == 0) __hip_atomic_store(&kdone[wid], 0x7FFFFFFF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) loads
     asm volatile("" :: "v"(junk));
     if ((DBG & 128) && prog && lane == 0) {
@@ -845,9 +687,9 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
 // ------------------------------------------------------------------ store prefilter: sampled thresholds
 // Every `stride`-th 32-row tile of the bf16 matrix / plane is scored against the launch's query planes (the same bf16
 // products as the scan, natural A loads: one wave per sampled tile, 24 K-steps x NQ2 MFMAs) and its maximum per query
-// kept: samp[tile][query].  Planes are in the scan's LDS layout and K order (RR_X3_ORDER_WIDE_BF16: position
-// 16 v + 8 h + j of a 32-dim block holds dim 16 h + 8 v + j), so lane half h of K-step s = 2 b + v multiplies the
-// row's dims 32 b + 16 h + 8 v .. + 7.
+// kept: samp[tile][query].  The planes are in memory order (what rr_scan_flt16 wants), so lane half h of the
+// 16-dim K-step s multiplies the row's dims 16 s + 8 h .. + 7.  (The sums run in another order than the scan's: the
+// difference sits inside the 2^-14 term of the bound, and sigma carries a 2.05 eps margin.)
 template <int NQ2>
 __global__ __launch_bounds__(512, 1) void rr_flt_sample(const u32x4* __restrict__ mat, const u32x4* __restrict__ plane,
                                                         int stride, int n_samp, float* __restrict__ samp) {
@@ -1063,6 +905,7 @@ static int rr_flt_ensure_shadow(rr_index* ix, hipStream_t st) {
     return RR_OK;
 }
 
+// RR_FLT_TUNE: debug-harness switches of the stamped rr_scan_flt16 variants only (32: one wave per SIMD)
 static int rr_flt_tune() {
     static const int t = getenv("RR_FLT_TUNE") ? atoi(getenv("RR_FLT_TUNE")) : 0;
     return t;
@@ -1131,8 +974,7 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
                            (uint32_t*)nullptr, 0u, rr_flt_tune());
     else
         hipLaunchKernelGGL((rr_scan_flt<NQ2, false>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
-                           reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy, 0, (int64_t)0,
-                           (uint32_t*)nullptr, 0u, rr_flt_tune());
+                           reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy);
     rr_scan_events_end(ix, slot, st);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
@@ -1282,8 +1124,7 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
         else
             hipLaunchKernelGGL((rr_scan_flt<4, false, DBG>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
                                reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128,
-                               (const float*)nullptr, (uint32_t*)nullptr, 0, (int64_t)0, reinterpret_cast<uint32_t*>(d_stamps), 0u,
-                               rr_flt_tune());
+                               (const float*)nullptr, (uint32_t*)nullptr);
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
         float ms = 0.f;
