@@ -74,6 +74,22 @@ def _torch():
     return torch
 
 
+class StagedTerms:
+    """Token ids of a batch already on the device (HybridSearcher.stage_batch)."""
+    __slots__ = ("ids", "off", "slot", "n_ids")
+
+    def __init__(self, ids, off, slot, n_ids):
+        self.ids, self.off, self.slot, self.n_ids = ids, off, slot, int(n_ids)
+
+
+class StagedBatch:
+    """One batch's inputs on the device: ``q`` (B, dim) float32, ``terms`` (StagedTerms or None), ``ready`` (event)."""
+    __slots__ = ("q", "terms", "ready", "slot")
+
+    def __init__(self, q, terms, ready, slot):
+        self.q, self.terms, self.ready, self.slot = q, terms, ready, slot
+
+
 class HybridSearcher:
     """K1 -> K2 -> K3 on one GPU over a ProductIndex (+ optional BM25Index)."""
 
@@ -86,8 +102,11 @@ class HybridSearcher:
         if not torch.cuda.is_available():
             raise _lib.HipLibraryError("no GPU visible: the search path runs on the device only")
         self.device = torch.device("cuda", index.device)
-        self._stage_slots = [{"host": None, "dev": None, "event": None} for _ in range(8)]
+        self._stage_slots = [{"host": None, "dev": None, "event": None, "consumed": None} for _ in range(8)]
         self._stage_next = 0
+        self._q_slots = [{"dev": None, "free": None} for _ in range(4)]
+        self._q_next = 0
+        self._in = None                       # input stream of stage_batch (created on first use)
 
     # -------------------------------------------------------------- device steps
     def _stream(self):
@@ -112,8 +131,10 @@ class HybridSearcher:
         """K2 on device tensors: float32 (B, pool) raw BM25 at the candidate rows."""
         torch = _torch()
         B, pool = rows_dev.shape
+        staged = isinstance(term_id_lists, StagedTerms)
         flat_form = isinstance(term_id_lists, tuple) and len(term_id_lists) == 2 and isinstance(term_id_lists[1], np.ndarray)
-        empty = (len(term_id_lists[0]) == 0) if flat_form else not any(len(t) for t in term_id_lists)
+        empty = (term_id_lists.n_ids == 0) if staged else \
+            (len(term_id_lists[0]) == 0) if flat_form else not any(len(t) for t in term_id_lists)
         if self.bm25 is None or empty:
             # no index / no tokens -> zeros (app/app_product_search.py:202,204)
             if out is None:
@@ -122,7 +143,7 @@ class HybridSearcher:
             return out
         if out is None:
             out = torch.empty((B, pool), dtype=torch.float32, device=self.device)
-        ids_dev, off_dev = self._stage_terms(term_id_lists)
+        ids_dev, off_dev = (term_id_lists.ids, term_id_lists.off) if staged else self._stage_terms(term_id_lists)[:2]
         _lib.check(self.lib.rr_bm25_scores_at_dev(
             self.bm25.handle, C.c_void_p(ids_dev.data_ptr()), C.c_void_p(off_dev.data_ptr()), B,
             C.c_void_p(rows_dev.data_ptr()), pool, {"forward": 0, "postings": 1}[mode],
@@ -151,6 +172,7 @@ class HybridSearcher:
         if slot["host"] is None or slot["host"].numel() < need:
             # (pinning host memory is slow and synchronises: every slot of the ring is sized at once, on first use)
             cap = max(2 * need, 16384)
+            torch.cuda.synchronize(self.device)      # (buffers change hands between streams only when nothing is in flight)
             for sl in self._stage_slots:
                 if sl["host"] is None or sl["host"].numel() < need:
                     if sl["event"] is not None:
@@ -163,9 +185,52 @@ class HybridSearcher:
         h = slot["host"].numpy()
         h[:n_off] = off
         h[n_off:n_off + n_ids] = flat
+        cur = torch.cuda.current_stream(self.device)
+        if slot["consumed"] is not None:         # (input stream: the K2 launch that read this device buffer last)
+            cur.wait_event(slot["consumed"])
+            slot["consumed"] = None
         slot["dev"][:need].copy_(slot["host"][:need], non_blocking=True)
-        slot["event"].record(torch.cuda.current_stream(self.device))
-        return slot["dev"][n_off:n_off + max(n_ids, 1)], slot["dev"][:n_off]
+        slot["event"].record(cur)
+        return slot["dev"][n_off:n_off + max(n_ids, 1)], slot["dev"][:n_off], slot, n_ids
+
+    def stage_batch(self, q_host, term_id_lists=None) -> "StagedBatch":
+        """Uploads one batch's inputs on the searcher's INPUT stream: the query vectors (``q_host``: pinned float32
+        (B, dim) tensor) into a device buffer of a small ring, the token ids through the pinned staging ring.  The
+        caller makes its compute stream wait for ``.ready``, runs the batch with ``.q`` / ``.terms`` and then calls
+        ``release(batch)`` (records when the buffers may be overwritten).  With the answer copied back on a third
+        stream, batch i + 1's uploads and batch i - 1's downloads run under batch i's kernels instead of between
+        them (~90 us per 256-query batch on one stream)."""
+        torch = _torch()
+        if self._in is None:
+            self._in = torch.cuda.Stream(device=self.device)
+        slot = self._q_slots[self._q_next % len(self._q_slots)]
+        self._q_next += 1
+        if slot["dev"] is None or slot["dev"].shape != q_host.shape:
+            # a fresh block of the caching allocator may still be read by kernels queued on the compute stream (it is
+            # free in THAT stream's order only): the input stream must not write it before they have run
+            slot["dev"] = torch.empty(tuple(q_host.shape), dtype=torch.float32, device=self.device)
+            slot["free"] = torch.cuda.Event()
+            slot["free"].record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._in):
+            if slot["free"] is not None:
+                self._in.wait_event(slot["free"])
+            slot["dev"].copy_(q_host, non_blocking=True)
+            terms = None
+            if term_id_lists is not None:
+                ids, off, tslot, n_ids = self._stage_terms(term_id_lists)
+                terms = StagedTerms(ids, off, tslot, n_ids)
+            ready = torch.cuda.Event()
+            ready.record(self._in)
+        return StagedBatch(slot["dev"], terms, ready, slot)
+
+    def release(self, batch: "StagedBatch") -> None:
+        """After the batch's kernels are enqueued on the current stream: its buffers are free once they have run."""
+        torch = _torch()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        batch.slot["free"] = ev
+        if batch.terms is not None:
+            batch.terms.slot["consumed"] = ev
 
     def fuse(self, params: "_lib.FuseParams", B: int, rows, dense, bm25, meta=None,
              rerank=None, best=None, gate=None):

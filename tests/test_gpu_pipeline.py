@@ -369,3 +369,38 @@ def test_module_level_run_search_shim_takes_the_eval_harness_call_shape(world, t
     assert a["sku"].tolist()[:10] == want["sku"].tolist()[:10]
     np.testing.assert_allclose(a["_final"].values, want["_final"].values, atol=TOL, rtol=0)
     assert list(a.columns) == [c for c in want.columns if c != "_row"]
+
+
+def test_staged_batches_on_the_input_stream_give_the_same_answers(world):
+    """HybridSearcher.stage_batch / release: a batch's queries and token ids go up on the searcher's input stream
+    (ring buffers, events), the compute stream waits for `.ready` -- several batches in flight, more batches than ring
+    slots, answers equal to the plain single-stream calls."""
+    import torch
+    from review_recommender_amd.sharded import ShardedSearcher
+    engine = SearchEngine(world["meta"], world["V"], world["blob"], normalize=False)
+    searcher = engine.searcher
+    sh = ShardedSearcher(searcher, world["n"], 0, 1)
+    w = FusionWeights(w_dense=0.5, w_bm25=0.5, w_rerank=0.0, w_prior=0.0, w_best=0.0, gate_penalty=1.0)
+    rng = np.random.default_rng(5)
+    words = synth.WORDS
+    batches = []
+    for b in range(11):                                  # more than the 4 query slots and the 8 token slots
+        B = 1 + (b * 37) % 70
+        q = torch.from_numpy(synth.unit_rows(B, 384, 100 + b)).pin_memory()
+        terms = [searcher.bm25.term_ids(list(rng.choice(words, size=int(rng.integers(0, 6))))) for _ in range(B)]
+        batches.append((q, terms))
+    plain = []
+    for q, terms in batches:
+        r, c, o = sh.search_batch_dev(q.to(searcher.device), terms, 10, w)
+        plain.append((r.cpu().numpy(), c.cpu().numpy(), o.cpu().numpy()))
+    cur = torch.cuda.current_stream(searcher.device)
+    outs = []
+    for q, terms in batches:                             # nothing synchronises between the batches
+        st = searcher.stage_batch(q, terms)
+        cur.wait_event(st.ready)
+        outs.append(sh.search_batch_dev(st.q, st.terms, 10, w))
+        searcher.release(st)
+    torch.cuda.synchronize()
+    for (r0, c0, o0), (r, c, o) in zip(plain, outs):
+        assert np.array_equal(r0, r.cpu().numpy()) and np.array_equal(o0, o.cpu().numpy())
+        assert np.array_equal(c0, c.cpu().numpy(), equal_nan=True)
