@@ -295,10 +295,11 @@ def main():
         pin_rows = torch.empty((args.batch, pool), dtype=torch.int64).pin_memory()
         pin_final = torch.empty((args.batch, pool), dtype=torch.float64).pin_memory()
 
-    # Three streams: batch i + 1's uploads (input stream of the searcher) and batch i - 1's downloads (out_stream) run
-    # under batch i's kernels; every byte still moves inside the timed region.  RR_BENCH_ONE_STREAM=1: everything on
-    # the compute stream, one after the other (A/B).
-    one_stream = os.environ.get("RR_BENCH_ONE_STREAM") is not None
+    # RR_BENCH_STREAMS=3 (A/B): batch i + 1's uploads on the searcher's input stream and batch i - 1's downloads on
+    # out_stream, under batch i's kernels.  Measured SLOWER than one stream on this stack (r02: 1.25M-row shard 0.79
+    # vs 0.69 ms per step, 10M rows 2.75 vs 2.72 ms: the cross-stream events cost more than the ~90 us of copies they
+    # hide), so the default keeps every copy on the compute stream, in order.
+    one_stream = os.environ.get("RR_BENCH_STREAMS") != "3"
     out_stream = torch.cuda.Stream(device=dev)
     pins = [(pin_rows, pin_order, pin_final),
             (torch.empty_like(pin_rows).pin_memory(), torch.empty_like(pin_order).pin_memory(),
