@@ -583,7 +583,16 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
         }
         // the last MFMAs' results are read by vector instructions below: the wait states the compiler would count for
         // its own MFMAs (at most 18 for any XDL write -> VALU read on gfx950; these are 4-pass)
-        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        // (the accumulators are operands of the wait itself: nothing that reads them can be scheduled in front of it)
+        if constexpr (NF == 8)
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[0][4]),
+                         "+v"(acc[0][5]), "+v"(acc[0][6]), "+v"(acc[0][7]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]),
+                         "+v"(acc[1][3]), "+v"(acc[1][4]), "+v"(acc[1][5]), "+v"(acc[1][6]), "+v"(acc[1][7]) :: "memory");
+        else if constexpr (NF == 4)
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]), "+v"(acc[1][0]),
+                         "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]) :: "memory");
+        else
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
         uint64_t ts1 = 0;
         if (DBG & 128) {
             ts1 = __builtin_amdgcn_s_memtime();
@@ -924,7 +933,7 @@ static int64_t rr_flt_smax_set_stride() { return (int64_t)RR_FLT_MAXQ * RR_MAX_S
 template <int NQ2, bool SCAN_BF16>
 static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const void* scan_mat, const float* d_q, int nq,
                            int pool, rr_flt_bounds bounds, hipStream_t st, const float** sigma_out,
-                           bool launch_scan = true) {
+                           bool launch_scan = true, bool allow_prefilter = true) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
     unsigned short* plane = reinterpret_cast<unsigned short*>(ix->d_qplanes) + (size_t)set * RR_FLT_MAXQ * 384;
@@ -943,7 +952,7 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
     uint32_t* dummy = nullptr;
     static const bool no_prefilter = getenv("RR_NO_PREFILTER") != nullptr;
     const int64_t n_tiles32 = (G.n_rows + 31) / 32;
-    if (SCAN_BF16 && !no_prefilter && G.n_rows >= 2000000) {
+    if (SCAN_BF16 && !no_prefilter && allow_prefilter && G.n_rows >= 2000000) {
         const int stride = 64;
         int64_t n_samp = (n_tiles32 - 1) / stride;
         if (n_samp > RR_FLT_SAMP_CAP) n_samp = RR_FLT_SAMP_CAP;
@@ -1023,9 +1032,14 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
     const bool dual = SCAN_BF16 && !no_dual;
     const rr_scan_geom G = rr_flt_geom<4, SCAN_BF16>(ix, dual);
     const float *sg0 = nullptr, *sg1 = nullptr;
-    int rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 0, G, scan_mat, d_q, nq_a, pool, bounds, st, &sg0, !dual);
+    // The store prefilter pays where the scan is HBM-bound (one set per launch: 1.41 -> 1.31 ms for 0.06 ms of sample
+    // and sigma).  The two-set launch is paced by the matrix side: there the skipped stores save 0.08 ms per launch and
+    // the two samples cost 0.125 (r02, same box: 2.74 -> 2.67 ms per step without them), so it runs without.
+    static const bool dual_prefilter = getenv("RR_DUAL_PREFILTER") != nullptr;
+    const bool pre = !dual || dual_prefilter;
+    int rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 0, G, scan_mat, d_q, nq_a, pool, bounds, st, &sg0, !dual, pre);
     if (rc != RR_OK) return rc;
-    rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 1, G, scan_mat, d_q + (int64_t)nq_a * ix->dim_pad, nq_b, pool, bounds, st, &sg1, !dual);
+    rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 1, G, scan_mat, d_q + (int64_t)nq_a * ix->dim_pad, nq_b, pool, bounds, st, &sg1, !dual, pre);
     if (rc != RR_OK) return rc;
     if (dual) {
         constexpr int THREADS = RR_FLT_THREADS(4);
