@@ -1,0 +1,59 @@
+"""The A/B switches of the batched dense path are read once per process: every one of them
+must give the same exact answer.  Each switch runs the same seeded search in a child process; the parent compares the
+answers with its own (default switches).  2.2M rows: above the store prefilter's 2M-row floor."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_ROWS, BATCH, POOL = 2_200_000, 256, 150
+
+CHILD = r"""
+import sys, json, hashlib
+import numpy as np, torch
+sys.path.insert(0, %r)
+from review_recommender_amd.index import ProductIndex
+n, b, pool = %d, %d, %d
+g = torch.Generator(device="cuda"); g.manual_seed(11)
+m = torch.randn((n, 384), device="cuda", generator=g); m /= m.norm(dim=1, keepdim=True)
+ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=m.data_ptr(), keepalive=m)
+q = np.random.default_rng(12).standard_normal((b, 384)).astype(np.float32)
+q /= np.linalg.norm(q, axis=1, keepdims=True)
+out = {}
+for nq in (b, 200, 130, 64):
+    rows, sims = ix.dense_topk(q[:nq], pool)
+    out[str(nq)] = [hashlib.sha256(np.ascontiguousarray(rows).tobytes()).hexdigest(),
+                    hashlib.sha256(np.ascontiguousarray(sims).tobytes()).hexdigest()]
+print("RESULT " + json.dumps(out))
+""" % (ROOT, N_ROWS, BATCH, POOL)
+
+
+def run_child(extra_env):
+    env = dict(os.environ)
+    env.update(extra_env)
+    p = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+@pytest.fixture(scope="module")
+def default_answer():
+    return run_child({})
+
+
+@pytest.mark.parametrize("switch", ["RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR", "RR_NO_PREFILTER",
+                                    "RR_NO_SHADOW"])
+def test_switch_gives_the_default_answer(default_answer, switch):
+    """rows AND scores bitwise: every filter path rescores its candidates with the single-query chain.  (RR_SCAN_EXACT is
+    not in the list: it serves with split-operand arithmetic, equal to fp32 rounding -- near-ties may swap; its parity
+    is checked against the oracle in test_gpu_dense.py.)"""
+    got = run_child({switch: "1"})
+    for nq, (rows_h, sims_h) in default_answer.items():
+        assert got[nq][0] == rows_h and got[nq][1] == sims_h, (switch, nq)
