@@ -280,6 +280,25 @@ int rr_ce_last_forward_ms(rr_ce* ce, float* out_ms);
  * (bit 0: no operand split, bit 1: no B-fragment reads, bit 2: no MFMA, bit 3: no lane swap).
  * Leaves garbage in the scan scratch; never part of a search. */
 int rr_debug_scan_x3w(rr_index* ix, int32_t variant, int32_t reps, float* out_ms);
+/* Two-phase K1 for ROW SHARDS (sharded.py: one process per GPU, this shard's rows in `ix`).  A shard's
+ * own top-`top_k` threshold sits far below the corpus-wide one (rank 150 of 1.25M rows ~ rank 1 200 of 10M), so a shard
+ * that selects on its own rescoring ~8x the candidates the merged answer needs.  Instead:
+ *   1. rr_dense_scan_dev: the scan of rr_dense_topk_dev without its selection; d_bound[q] (device, n_queries floats) =
+ *      a lower bound of the score of this shard's `kth`-best row (kth = ceil(top_k / shards)), or -inf;
+ *   2. the caller takes the MINIMUM of d_bound over the shards (one all-reduce of n_queries floats): the union of the
+ *      shards' kth best rows holds >= top_k rows, so that minimum is a lower bound of the corpus-wide top_k-th best score;
+ *   3. rr_dense_select_dev: the selection, opening nothing that cannot reach that floor.  Its lists still hold top_k
+ *      rows per query -- every row of the corpus-wide top-k that lives in this shard, filled up with other exactly
+ *      scored rows of the shard (not necessarily its next best): only the MERGED top-k of all shards is the answer.
+ * `*applied` (host) = 0 when the call cannot be split (fewer than 5 or more than 256 queries, 129..192, a small or
+ * non-finite matrix, a pinned scan mode): nothing was launched, d_bound is untouched, use rr_dense_topk_dev.  The
+ * queries, n_queries and top_k of phase 2 must be those of phase 1, with no other search on `ix` in between.
+ * (Replaces nothing in the reference: utils.py:111-124 is single-process.) */
+int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t top_k, int32_t kth,
+                      float* d_bound, int32_t* applied, void* stream);
+int rr_dense_select_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t top_k,
+                        const float* d_floor, int64_t* d_out_rows, float* d_out_scores, void* stream);
+
 /* The same for the 128-query fp32 filter scan (bit 0: no epilogue, bit 1: no B-fragment reads, bit 2: no
  * MFMA, bit 3: no lane swaps / conversions). */
 int rr_debug_scan_flt(rr_index* ix, int32_t variant, int32_t reps, float* out_ms);

@@ -50,6 +50,8 @@ PROTOTYPES = {
     "rr_index_set_shadow": (C.c_int, [c_vp, c_i32]),
     "rr_index_set_scan_mode": (C.c_int, [c_vp, c_i32]),
     "rr_debug_scan_x3w": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
+    "rr_dense_scan_dev": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, P(c_i32), c_vp]),
+    "rr_dense_select_dev": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rr_debug_scan_flt": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
     "rr_bm25_create": (C.c_int, [c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_vp, c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, P(c_vp)]),

@@ -186,7 +186,7 @@ extern "C" int rr_index_destroy(rr_index* ix) {
     if (ix->d_matrix && ix->owns_matrix) hipFree(ix->d_matrix);
     hipFree(ix->d_n_reviews); hipFree(ix->d_avg_stars); hipFree(ix->d_log1p_n);
     hipFree(ix->d_sims); hipFree(ix->d_gmax); hipFree(ix->d_smax); hipFree(ix->d_sel_trace); hipFree(ix->d_qplanes); hipFree(ix->d_x3); hipFree(ix->d_q);
-    hipFree(ix->d_rows_out); hipFree(ix->d_scores_out); hipFree(ix->d_shadow); hipFree(ix->d_flt_samp); hipFree(ix->d_flt_sigma); hipFree(ix->d_flt_prog);
+    hipFree(ix->d_rows_out); hipFree(ix->d_scores_out); hipFree(ix->d_shadow); hipFree(ix->d_flt_samp); hipFree(ix->d_flt_sigma); hipFree(ix->d_flt_prog); free(ix->flt_pending);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);
     if (ix->ev_done) hipEventDestroy(ix->ev_done);

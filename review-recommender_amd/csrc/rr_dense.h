@@ -68,11 +68,14 @@ size_t rr_x3_scratch_bytes();
 // `nq_b` > 0: the launch covers TWO scan launches (sets) of the same geometry: queries [0, nq) come from set 0, [nq,
 // nq + nq_b) from set 1, whose tile / group maxima sit `set_stride_words` 4-byte words behind set 0's and whose eps /
 // sigma entries start at index RR_FLT_MAXQ.
+// `floor` (device, per query of the launch, may be null): row shards -- a lower bound of the corpus-wide pool-th best score.
 void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st,
                              const float* eps = nullptr, const float* sigma = nullptr, int nq_b = 0,
-                             int64_t mmax_set_stride = 0, int64_t smax_set_stride = 0);
+                             int64_t mmax_set_stride = 0, int64_t smax_set_stride = 0, const float* floor = nullptr);
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
-                               float* d_scores, hipStream_t st);
+                               float* d_scores, hipStream_t st, bool floor_mode = false);
+void rr_launch_group_kth(rr_index* ix, const rr_scan_geom& G, int nq_a, int nq_b, int kth, const float* eps, float* d_bound,
+                         int64_t smax_set_stride, hipStream_t st);
 // Waves a kernel can keep resident on the device (occupancy x CUs x waves per workgroup).
 int rr_resident_waves(const void* kernel, int threads, int device);
 // bf16-storage scans (rr_dense_bf16.hip): up to 8 (VALU) or 9..64 (matrix cores) queries.
@@ -87,7 +90,12 @@ int rr_dense_chunk_x3(rr_index* ix, const float* d_q, int nq, int pool, int64_t*
                       float* d_scores, hipStream_t st);
 // bf16 filter scan + exact per-row-chain rescoring, 5..128 queries (rr_dense_flt.hip); RR_FLT_NO_BOUND when
 // the matrix has no finite row-norm bound
+// `phase`: 0 = scan + selection; 1 = scan only, bound[q] (rr_group_kth with `kth`) written, state kept in the index;
+// 2 = selection of the scan phase 1 left behind, with `floor` (row shards)
 int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
-                       float* d_scores, hipStream_t st);
+                       float* d_scores, hipStream_t st, int phase = 0, int kth = 0, float* d_bound = nullptr,
+                       const float* d_floor = nullptr);
+// any other search on the index makes a parked phase-1 scan void
+void rr_flt_drop_pending(rr_index* ix);
 // fp32 rows (device, n x dim) -> the index's bf16 matrix rows [first, first + n), optional l2 normalise
 int rr_store_rows_bf16(rr_index* ix, int64_t first_row, int64_t n, float* d_rows_f32, float eps, hipStream_t st);

@@ -594,7 +594,7 @@ __device__ void rr_rank_sort_desc(const uint64_t* keys, int n, uint64_t* out) {
 template <typename GroupKeyAt>
 __device__ uint32_t rr_sel_open_groups(GroupKeyAt group_key_at, int ng, int pool, uint32_t (*cnt)[3][16],
                                        int& phase, uint32_t* counters, uint32_t* list2,
-                                       float eps2 = -1.f, uint32_t* open_key = nullptr) {
+                                       float eps2 = -1.f, uint32_t* open_key = nullptr, uint32_t thr_floor = 0u) {
     const int tid = threadIdx.x;
     uint32_t r[RR_SEL_RK];
     int n_mine = 0;
@@ -618,6 +618,7 @@ __device__ uint32_t rr_sel_open_groups(GroupKeyAt group_key_at, int ng, int pool
     if (eps2 >= 0.f) {
         thr = rr_f2key(rr_key2f(tau) - eps2);          // (-inf - x = -inf; a NaN bound gives key(NaN): see caller)
         if (thr == 0u) thr = 1u;
+        if (thr_floor > thr) thr = thr_floor;          // row shards: the corpus-wide lower bound opens fewer groups
         if (open_key) *open_key = thr;
     }
 #pragma unroll
@@ -769,7 +770,8 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
     rr_scan_geom G, const float* __restrict__ mmax, const uint32_t* __restrict__ smax, int pool,
     uint32_t* __restrict__ out_mtiles, int32_t* __restrict__ out_count, uint32_t* __restrict__ out_tau,
     int32_t* __restrict__ fb, int32_t* __restrict__ dbg, const float* __restrict__ eps,
-    const float* __restrict__ sigma, int nq_a, int nq_b, int64_t mmax_set_stride, int64_t smax_set_stride) {
+    const float* __restrict__ sigma, int nq_a, int nq_b, int64_t mmax_set_stride, int64_t smax_set_stride,
+    const float* __restrict__ floor) {      // [nq_a + nq_b] or null: a lower bound of the corpus-wide pool-th best SCORE
     __shared__ uint32_t cnt[2][3][16];
     __shared__ uint32_t counters[4];
     __shared__ uint32_t list2[RR_SEL_LCAP];
@@ -804,7 +806,11 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
         const float e = eps ? eps[q] : -1.f;
         if (eps && !(e >= 0.f && e < 3.0e38f)) ok = false;     // no finite bound for this query
         if (ok) {
-            tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2, eps ? 2.05f * e : -1.f, &open);
+            // (row shards, DESIGN.md section 5: a row of the corpus-wide top-pool has score >= floor, hence filter score
+            //  >= floor - e: nothing below floor - 1.05 e has to be opened, whatever this shard's own threshold says)
+            const float fl = (floor && eps) ? floor[Q] - 1.05f * e : -INFINITY;
+            tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2, eps ? 2.05f * e : -1.f, &open,
+                                     fl == fl ? rr_f2key(fl) : 0u);
             if (!eps) open = tau;
             else tau = rr_f2key(rr_key2f(tau) - 1.02f * e);
             if (tau == 0u) tau = 1u;
@@ -911,7 +917,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
     rr_scan_geom G, const uint32_t* __restrict__ mtiles, const int32_t* __restrict__ count,
     const uint32_t* __restrict__ tau_of, const float* __restrict__ sc, int pool, int64_t row_offset,
     int64_t* __restrict__ out_rows, float* __restrict__ out_scores, int32_t* __restrict__ fb,
-    int32_t* __restrict__ dbg) {
+    int32_t* __restrict__ dbg, int floor_mode) {
     __shared__ uint32_t counters[2];
     __shared__ uint64_t cand[RR_SEL_CCAP];
     const int tid = threadIdx.x;
@@ -935,7 +941,28 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
         }
     }
     __syncthreads();
-    const uint32_t n_cand = counters[0];
+    uint32_t n_cand = counters[0];
+    if (floor_mode && n_cand < (uint32_t)pool && (uint32_t)n1 <= RR_SEL_CCAP / 2) {
+        // Row shards with a corpus-wide floor: fewer M-tiles were opened than this shard's own top-pool needs, so fewer
+        // than `pool` rows may reach its own cut.  Every row of the corpus-wide top-pool that lives here IS among the
+        // rescored rows; the list is filled up with the best of the other rescored rows (exact scores, below the
+        // corpus-wide cut: the merge never takes them).
+        __syncthreads();
+        if (tid == 0) counters[0] = 0;
+        __syncthreads();
+        for (int i = tid; i < n1; i += RR_SEL_THREADS) {
+            const int64_t at = (int64_t)q * RR_X3_MCAP + (i >> sh);
+            const int r = i & ((1 << sh) - 1);
+            const uint32_t row = (mtiles[at] << sh) + (uint32_t)r;
+            if ((int64_t)row < G.n_rows) {
+                const uint32_t key = rr_f2key(sc[(at << sh) + r]);
+                const uint32_t slot = atomicAdd(&counters[0], 1u);
+                if (slot < RR_SEL_CCAP / 2) cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - row);
+            }
+        }
+        __syncthreads();
+        n_cand = counters[0];
+    }
     if (tid == 0) dbg[q * 16 + 3] = (int32_t)n_cand;
     if (n_cand > RR_SEL_CCAP / 2 || n_cand < (uint32_t)pool) {    // massive ties at the cut
         if (tid == 0) {
@@ -979,17 +1006,63 @@ size_t rr_x3_scratch_bytes() {
            sizeof(float) * (size_t)RR_SEL_MAXQ * RR_X3_MCAP * 16;
 }
 void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int pool, hipStream_t st, const float* eps,
-                             const float* sigma, int nq_b, int64_t mmax_set_stride, int64_t smax_set_stride) {
+                             const float* sigma, int nq_b, int64_t mmax_set_stride, int64_t smax_set_stride,
+                             const float* floor) {
     const rr_x3_scratch s = rr_x3_scratch_of(ix);
     hipLaunchKernelGGL(rr_select_mtiles, dim3(nq + nq_b), dim3(RR_SEL_THREADS), 0, st, G, ix->d_gmax, ix->d_smax, pool,
                        s.mtiles, s.count, s.tau, s.fb, ix->d_sel_trace, eps, sigma, nq, nq_b, mmax_set_stride,
-                       smax_set_stride);
+                       smax_set_stride, floor);
 }
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
-                               float* d_scores, hipStream_t st) {
+                               float* d_scores, hipStream_t st, bool floor_mode) {
     const rr_x3_scratch s = rr_x3_scratch_of(ix);
     hipLaunchKernelGGL(rr_select_rescored, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, s.mtiles, s.count, s.tau,
-                       s.sc, pool, ix->row_offset, d_rows, d_scores, s.fb, ix->d_sel_trace);
+                       s.sc, pool, ix->row_offset, d_rows, d_scores, s.fb, ix->d_sel_trace, floor_mode ? 1 : 0);
+}
+
+// bound[Q] = (a lower bound of) the kth largest group maximum of the filter scores of query Q, minus 1.01 eps: at least
+// kth rows of this matrix have a SCORE >= bound[Q].  Row shards exchange the minimum of these (kth = ceil(pool / shards):
+// the union of the shards' kth best groups holds >= pool rows), which is then a lower bound of the corpus-wide pool-th
+// best score -- rr_select_mtiles' `floor`.  -inf where there are no more than kth groups or no finite eps.
+__global__ __launch_bounds__(RR_SEL_THREADS) void rr_group_kth(rr_scan_geom G, const uint32_t* __restrict__ smax, int kth,
+                                                               const float* __restrict__ eps, float* __restrict__ bound,
+                                                               int nq_a, int nq_b, int64_t smax_set_stride) {
+    __shared__ uint32_t cnt[2][3][16];
+    const int tid = threadIdx.x;
+    const int Q = blockIdx.x;
+    const int set = (nq_b > 0 && Q >= nq_a) ? 1 : 0;
+    const int q = set ? Q - nq_a : Q;
+    smax += set * smax_set_stride;
+    eps += set * RR_FLT_MAXQ;
+    const int QS = G.qs;
+    const int gpw = G.gpw > 1 ? G.gpw : 1;
+    const int ng = G.n_waves * gpw;
+    int phase = 0;
+    float out = -INFINITY;
+    if (ng > kth && ng <= RR_SEL_RK * RR_SEL_THREADS) {      // (uniform)
+        uint32_t r[RR_SEL_RK];
+        int n_mine = 0;
+#pragma unroll
+        for (int j = 0; j < RR_SEL_RK; ++j) {
+            const int i = tid + j * RR_SEL_THREADS;
+            r[j] = i < ng ? smax[(int64_t)i * QS + q] : 0u;
+            n_mine += i < ng ? 1 : 0;
+        }
+        uint32_t tau;
+        if (ng <= 1 * RR_SEL_THREADS) tau = rr_kth_largest_reg<1>(r, n_mine, (uint32_t)kth, cnt, phase, 7);
+        else if (ng <= 2 * RR_SEL_THREADS) tau = rr_kth_largest_reg<2>(r, n_mine, (uint32_t)kth, cnt, phase, 7);
+        else if (ng <= 4 * RR_SEL_THREADS) tau = rr_kth_largest_reg<4>(r, n_mine, (uint32_t)kth, cnt, phase, 7);
+        else tau = rr_kth_largest_reg<8>(r, n_mine, (uint32_t)kth, cnt, phase, 7);
+        const float e = eps[q];
+        if (tau > 0x007FFFFFu && e >= 0.f && e < 3.0e38f) out = rr_key2f(tau) - 1.01f * e;
+        if (!(out == out)) out = -INFINITY;
+    }
+    if (tid == 0) bound[Q] = out;
+}
+void rr_launch_group_kth(rr_index* ix, const rr_scan_geom& G, int nq_a, int nq_b, int kth, const float* eps, float* d_bound,
+                         int64_t smax_set_stride, hipStream_t st) {
+    hipLaunchKernelGGL(rr_group_kth, dim3(nq_a + nq_b), dim3(RR_SEL_THREADS), 0, st, G, ix->d_smax, kth, eps, d_bound, nq_a,
+                       nq_b, smax_set_stride);
 }
 
 // ------------------------------------------------------------------ l2 normalize
@@ -1256,6 +1329,56 @@ __global__ void rr_pad_queries(const float* __restrict__ src, float* __restrict_
     dst[i] = (qi < nq && c < dim) ? src[(int64_t)qi * dim + c] : 0.f;
 }
 
+// Two-phase K1 for row shards (include/rr_hip.h): phase 1 = pad + prepare + scan + per-query bound.
+extern "C" int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t pool, int32_t kth,
+                                 float* d_bound, int32_t* applied, void* stream) {
+    RR_REQUIRE(ix && d_queries && d_bound && applied, "rr_dense_scan_dev: NULL argument");
+    RR_REQUIRE(n_queries >= 1 && n_queries <= RR_MAX_BATCH, "rr_dense_scan_dev: n_queries %d out of [1,%d]", n_queries, RR_MAX_BATCH);
+    RR_REQUIRE(pool >= 1 && pool <= RR_MAX_POOL && pool <= ix->n_rows, "rr_dense_scan_dev: pool %d out of range", pool);
+    RR_REQUIRE(kth >= 1 && kth <= pool, "rr_dense_scan_dev: kth %d out of [1, pool]", kth);
+    RR_REQUIRE(ix->d_matrix, "rr_dense_scan_dev: index has no matrix");
+    *applied = 0;
+    std::lock_guard<std::mutex> lk(ix->mu);
+    RR_HIP_TRY(hipSetDevice(ix->device));
+    // only the batched filter path has a scan that can be split from its selection (5 .. 256 queries, matrix-core
+    // kernels, default scan mode); everything else answers "not applied" and is served by rr_dense_topk_dev
+    static const bool exact_scan = getenv("RR_SCAN_EXACT") != nullptr, f32_chain = getenv("RR_SCAN_F32_CHAIN") != nullptr;
+    const bool mfma_ok = ix->dim_pad == 384 && ix->n_rows >= 64;
+    if (!mfma_ok || n_queries <= 4 || n_queries > RR_SEL_MAXQ || exact_scan || f32_chain || ix->scan_mode != RR_SCAN_MODE_DEFAULT ||
+        (n_queries > RR_FLT_MAXQ && n_queries <= RR_FLT_MAXQ + RR_MFMA_MAXQ))       // (129 .. 192 go as two chunks)
+        return RR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = rr_scratch_enter(ix, st);
+    if (rc) return rc;
+    rc = rr_ensure_scratch(ix, RR_MFMA_MAXQ);
+    if (rc) return rc;
+    const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);
+    const int64_t total = (int64_t)slots * ix->dim_pad;
+    hipLaunchKernelGGL(rr_pad_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       d_queries, ix->d_q, n_queries, ix->dim, ix->dim_pad, slots);
+    rc = rr_dense_chunk_flt(ix, ix->d_q, n_queries, pool, nullptr, nullptr, st, 1, kth, d_bound, nullptr);
+    if (rc == RR_FLT_NO_BOUND || rc == RR_FLT_SMALL) return rr_scratch_leave(ix, st);     // not applied
+    if (rc) return rc;
+    *applied = 1;
+    return rr_scratch_leave(ix, st);
+}
+
+// phase 2 = selection / rescoring / ordering of the scan phase 1 left behind, M-tiles opened no further down than `d_floor`
+extern "C" int rr_dense_select_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t pool,
+                                   const float* d_floor, int64_t* d_out_rows, float* d_out_scores, void* stream) {
+    RR_REQUIRE(ix && d_queries && d_out_rows && d_out_scores, "rr_dense_select_dev: NULL argument");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    RR_HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = rr_scratch_enter(ix, st);
+    if (rc) return rc;
+    rc = rr_dense_chunk_flt(ix, ix->d_q, n_queries, pool, d_out_rows, d_out_scores, st, 2, 0, nullptr, d_floor);
+    RR_REQUIRE(rc != RR_FLT_SMALL, "rr_dense_select_dev: no scan of these %d queries (pool %d) is pending: call rr_dense_scan_dev "
+               "first and use its `applied` answer", n_queries, pool);
+    if (rc) return rc;
+    return rr_scratch_leave(ix, st);
+}
+
 extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n_queries,
                                  int32_t pool, int64_t* d_out_rows, float* d_out_scores,
                                  void* stream) {
@@ -1271,6 +1394,7 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
+    rr_flt_drop_pending(ix);
     int rc = rr_scratch_enter(ix, st);
     if (rc) return rc;
     const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);   // kernels read whole query tiles

@@ -992,13 +992,13 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
 // selection + rescoring + ordering + per-64 fallback over nq_a (+ nq_b) queries of one (two) scan launches
 template <bool ROWS_BF16>
 static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, int nq_a, int nq_b, int pool,
-                         int64_t* d_rows, float* d_scores, const float* sigma, hipStream_t st) {
+                         int64_t* d_rows, float* d_scores, const float* sigma, hipStream_t st, const float* floor = nullptr) {
     const rr_x3_scratch X = rr_x3_scratch_of(ix);
     const int nq = nq_a + nq_b;
-    rr_launch_select_mtiles(ix, G, nq_a, pool, st, X.eps, sigma, nq_b, rr_flt_mmax_set_stride(G), rr_flt_smax_set_stride());
+    rr_launch_select_mtiles(ix, G, nq_a, pool, st, X.eps, sigma, nq_b, rr_flt_mmax_set_stride(G), rr_flt_smax_set_stride(), floor);
     hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
                        X.mtiles, X.count, X.fb, X.sc);
-    rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st);
+    rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st, floor != nullptr);
     RR_HIP_TRY(hipGetLastError());
     // Flagged queries: the stored-score pass of the split-operand scan, 64 queries at a time; every
     // launch in it returns at once when no flag of its queries is up.
@@ -1011,20 +1011,56 @@ static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, 
     return RR_OK;
 }
 
+// What phase 1 of a two-phase call (row shards: scan, exchange a bound, select) leaves for phase 2.
+struct rr_flt_pending {
+    bool valid;
+    rr_scan_geom G;
+    const float* d_q;
+    int nq_a, nq_b, pool;
+    const float* sigma;
+    bool rows_bf16;
+};
+struct rr_flt_phase {            // how a chunk function was called
+    int phase = 0;               // 0 both, 1 scan only (+ bound), 2 selection only
+    int kth = 0;
+    float* d_bound = nullptr;
+    const float* d_floor = nullptr;
+};
+static rr_flt_pending* rr_flt_pending_of(rr_index* ix) {
+    if (!ix->flt_pending) ix->flt_pending = calloc(1, sizeof(rr_flt_pending));
+    return static_cast<rr_flt_pending*>(ix->flt_pending);
+}
+void rr_flt_drop_pending(rr_index* ix) {
+    if (ix->flt_pending) static_cast<rr_flt_pending*>(ix->flt_pending)->valid = false;
+}
+// the tail of every scan path: straight on to the selection, or park the state for phase 2
+template <bool ROWS_BF16>
+static int rr_flt_after_scan(rr_index* ix, const rr_scan_geom& G, const float* d_q, int nq_a, int nq_b, int pool,
+                             int64_t* d_rows, float* d_scores, const float* sigma, hipStream_t st, const rr_flt_phase& ph) {
+    if (ph.phase != 1) return rr_flt_finish<ROWS_BF16>(ix, G, d_q, nq_a, nq_b, pool, d_rows, d_scores, sigma, st);
+    rr_flt_pending* p = rr_flt_pending_of(ix);
+    if (!p) return RR_E_HIP;
+    *p = rr_flt_pending{true, G, d_q, nq_a, nq_b, pool, sigma, ROWS_BF16};
+    rr_launch_group_kth(ix, G, nq_a, nq_b, ph.kth, rr_x3_scratch_of(ix).eps, ph.d_bound, rr_flt_smax_set_stride(), st);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
 template <int NQ2, bool SCAN_BF16, bool ROWS_BF16>
 static int rr_dense_chunk_flt_t(rr_index* ix, const void* scan_mat, const float* d_q, int nq, int pool, int64_t* d_rows,
-                                float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
+                                float* d_scores, rr_flt_bounds bounds, hipStream_t st, const rr_flt_phase& ph = rr_flt_phase()) {
     const rr_scan_geom G = rr_flt_geom<NQ2, SCAN_BF16>(ix);
     const float* sigma = nullptr;
     const int rc = rr_flt_scan_set<NQ2, SCAN_BF16>(ix, 0, G, scan_mat, d_q, nq, pool, bounds, st, &sigma);
     if (rc != RR_OK) return rc;
-    return rr_flt_finish<ROWS_BF16>(ix, G, d_q, nq, 0, pool, d_rows, d_scores, sigma, st);
+    return rr_flt_after_scan<ROWS_BF16>(ix, G, d_q, nq, 0, pool, d_rows, d_scores, sigma, st, ph);
 }
 
 // 129 .. 256 queries whose second part still fills a 128-slot launch (> 64 queries): two scan launches, one selection
 template <bool SCAN_BF16, bool ROWS_BF16>
 static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* d_q, int nq_a, int nq_b, int pool,
-                               int64_t* d_rows, float* d_scores, rr_flt_bounds bounds, hipStream_t st) {
+                               int64_t* d_rows, float* d_scores, rr_flt_bounds bounds, hipStream_t st,
+                               const rr_flt_phase& ph = rr_flt_phase()) {
     // bf16 stream: both sets in ONE launch, the matrix leaves HBM once for the 256 queries (rr_scan_flt<.., DUAL>).
     // RR_NO_DUAL=1: two launches back to back (A/B).  An fp32 stream (no plane) keeps the two launches: its ring is
     // two segments per M-tile and the pair's lock-step window would be twice as wide.
@@ -1062,11 +1098,24 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
         rr_scan_events_end(ix, slot, st);
         RR_HIP_TRY(hipGetLastError());
     }
-    return rr_flt_finish<ROWS_BF16>(ix, G, d_q, nq_a, nq_b, pool, d_rows, d_scores, sg0, st);
+    return rr_flt_after_scan<ROWS_BF16>(ix, G, d_q, nq_a, nq_b, pool, d_rows, d_scores, sg0, st, ph);
 }
 
 int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
-                       float* d_scores, hipStream_t st) {
+                       float* d_scores, hipStream_t st, int phase, int kth, float* d_bound, const float* d_floor) {
+    if (phase == 2) {
+        // selection of the scan a phase-1 call left behind (same queries, same pool), with the exchanged floor
+        rr_flt_pending* p = rr_flt_pending_of(ix);
+        if (!p || !p->valid || p->nq_a + p->nq_b != nq || p->pool != pool || p->d_q != d_q) return RR_FLT_SMALL;   // (caller: plain call)
+        p->valid = false;
+        return p->rows_bf16 ? rr_flt_finish<true>(ix, p->G, d_q, p->nq_a, p->nq_b, pool, d_rows, d_scores, p->sigma, st, d_floor)
+                            : rr_flt_finish<false>(ix, p->G, d_q, p->nq_a, p->nq_b, pool, d_rows, d_scores, p->sigma, st, d_floor);
+    }
+    rr_flt_phase ph;
+    ph.phase = phase;
+    ph.kth = kth;
+    ph.d_bound = d_bound;
+    if (ix->flt_pending) static_cast<rr_flt_pending*>(ix->flt_pending)->valid = false;
     // A small matrix has too few tile groups for the threshold to mean anything (every query would be
     // flagged): the caller runs the per-row-chain VALU scans instead, which cost microseconds there and
     // keep the answer bitwise equal to what a large index (or the unsharded one) gives through rescoring.
@@ -1085,10 +1134,10 @@ int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t
             rc = rr_flt_ensure_shadow(ix, st);
             if (rc != RR_OK) return rc;
             if (ix->shadow_valid)
-                return rr_dense_pair_flt_t<true, false>(ix, ix->d_shadow, d_q, nq_a, nq_b, pool, d_rows, d_scores, nb, st);
+                return rr_dense_pair_flt_t<true, false>(ix, ix->d_shadow, d_q, nq_a, nq_b, pool, d_rows, d_scores, nb, st, ph);
         }
-        return b ? rr_dense_pair_flt_t<true, true>(ix, ix->d_matrix, d_q, nq_a, nq_b, pool, d_rows, d_scores, nb, st)
-                 : rr_dense_pair_flt_t<false, false>(ix, ix->d_matrix, d_q, nq_a, nq_b, pool, d_rows, d_scores, nb, st);
+        return b ? rr_dense_pair_flt_t<true, true>(ix, ix->d_matrix, d_q, nq_a, nq_b, pool, d_rows, d_scores, nb, st, ph)
+                 : rr_dense_pair_flt_t<false, false>(ix, ix->d_matrix, d_q, nq_a, nq_b, pool, d_rows, d_scores, nb, st, ph);
     }
     if (!b && ix->use_shadow && !no_shadow) {
         // fp32 storage: the scan streams the bf16 filter plane (half the bytes per launch; the approximate scores
@@ -1097,20 +1146,20 @@ int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t
         if (rc != RR_OK) return rc;
         if (ix->shadow_valid) {
             const void* sm = ix->d_shadow;
-            if (nq <= 32) return rr_dense_chunk_flt_t<1, true, false>(ix, sm, d_q, nq, pool, d_rows, d_scores, nb, st);
-            if (nq <= 64) return rr_dense_chunk_flt_t<2, true, false>(ix, sm, d_q, nq, pool, d_rows, d_scores, nb, st);
-            return rr_dense_chunk_flt_t<4, true, false>(ix, sm, d_q, nq, pool, d_rows, d_scores, nb, st);
+            if (nq <= 32) return rr_dense_chunk_flt_t<1, true, false>(ix, sm, d_q, nq, pool, d_rows, d_scores, nb, st, ph);
+            if (nq <= 64) return rr_dense_chunk_flt_t<2, true, false>(ix, sm, d_q, nq, pool, d_rows, d_scores, nb, st, ph);
+            return rr_dense_chunk_flt_t<4, true, false>(ix, sm, d_q, nq, pool, d_rows, d_scores, nb, st, ph);
         }
     }
     const void* m = ix->d_matrix;
     if (nq <= 32)
-        return b ? rr_dense_chunk_flt_t<1, true, true>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st)
-                 : rr_dense_chunk_flt_t<1, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st);
+        return b ? rr_dense_chunk_flt_t<1, true, true>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st, ph)
+                 : rr_dense_chunk_flt_t<1, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st, ph);
     if (nq <= 64)
-        return b ? rr_dense_chunk_flt_t<2, true, true>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st)
-                 : rr_dense_chunk_flt_t<2, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st);
-    return b ? rr_dense_chunk_flt_t<4, true, true>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st)
-             : rr_dense_chunk_flt_t<4, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st);
+        return b ? rr_dense_chunk_flt_t<2, true, true>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st, ph)
+                 : rr_dense_chunk_flt_t<2, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st, ph);
+    return b ? rr_dense_chunk_flt_t<4, true, true>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st, ph)
+             : rr_dense_chunk_flt_t<4, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st, ph);
 }
 
 // Timing-only ablations of the 128-query fp32 filter scan (tools/flt_ablate.py).  Garbage in the scratch afterwards.

@@ -127,6 +127,34 @@ class HybridSearcher:
                                               self._stream()), "rr_dense_topk_dev")
         return rows, dense
 
+    def dense_scan(self, q_dev, pool: int, kth: int):
+        """Phase 1 of the two-phase K1 of row shards (rr_dense_scan_dev): the scan without its selection.  Returns a
+        float32 (B,) device tensor -- per query a lower bound of the score of this shard's kth-best row -- or None when
+        the call cannot be split (then use dense_pool)."""
+        torch = _torch()
+        B = q_dev.shape[0]
+        bound = torch.full((B,), float("-inf"), dtype=torch.float32, device=self.device)
+        applied = C.c_int32(0)
+        _lib.check(self.lib.rr_dense_scan_dev(self.index.handle, C.c_void_p(q_dev.data_ptr()), B, pool, int(kth),
+                                              C.c_void_p(bound.data_ptr()), C.byref(applied), self._stream()),
+                   "rr_dense_scan_dev")
+        return bound if applied.value else None
+
+    def dense_select(self, q_dev, pool: int, floor, out=None):
+        """Phase 2 (rr_dense_select_dev): the selection of the scan dense_scan left behind, with the floor the shards
+        agreed on (float32 (B,) device tensor).  Lists of `pool` rows: see include/rr_hip.h."""
+        torch = _torch()
+        B = q_dev.shape[0]
+        if out is not None:
+            rows, dense = out
+        else:
+            rows = torch.empty((B, pool), dtype=torch.int64, device=self.device)
+            dense = torch.empty((B, pool), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.rr_dense_select_dev(self.index.handle, C.c_void_p(q_dev.data_ptr()), B, pool,
+                                                C.c_void_p(floor.data_ptr()), C.c_void_p(rows.data_ptr()),
+                                                C.c_void_p(dense.data_ptr()), self._stream()), "rr_dense_select_dev")
+        return rows, dense
+
     def bm25_at(self, term_id_lists: Sequence[Sequence[int]], rows_dev, mode: str = "forward", out=None):
         """K2 on device tensors: float32 (B, pool) raw BM25 at the candidate rows."""
         torch = _torch()

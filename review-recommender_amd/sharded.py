@@ -17,6 +17,7 @@ the local top-pools, and a row's score does not depend on the shard it sits in
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -94,6 +95,22 @@ def exchange(buf, world: int, group=None):
     return out
 
 
+def exchange_floor(bound, world: int, group=None):
+    """The tiny collective in front of the shards' selection: element-wise MINIMUM over the ranks
+    of the per-query bounds of HybridSearcher.dense_scan -- a lower bound of the corpus-wide pool-th best score.
+    In place; B floats."""
+    import torch.distributed as dist
+    if world == 1:
+        return bound
+    if dist.get_backend(group) == "nccl" or not bound.is_cuda:
+        dist.all_reduce(bound, op=dist.ReduceOp.MIN, group=group)
+    else:                                                         # gloo rehearsal on a GPU box
+        host = bound.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
+        bound.copy_(host)
+    return bound
+
+
 def split_pairs(n_pairs: int, world: int, rank: int) -> Tuple[int, int]:
     """Even split of the flattened (query, candidate) pair list of the rerank step across ranks
     ("pairs B x 200 are split evenly across ranks after the merge"): the same rule as shard_bounds."""
@@ -139,16 +156,39 @@ class ShardedSearcher:
         self.s, self.rank, self.world, self.group, self.n_total = searcher, rank, world, group, n_total_rows
         # diagnostic: run the payload + exchange + merge path even with one rank (bench.py --force-payload)
         self.force_payload = False
+        # row shards select against a corpus-wide floor (two-phase K1 + exchange_floor); RR_NO_SHARD_FLOOR=1: every shard
+        # selects on its own threshold (one collective less, ~8x the rescoring at 8 shards)
+        self.use_floor = os.environ.get("RR_NO_SHARD_FLOOR") is None
 
-    def local_payload(self, q_dev, term_id_lists, pool_local: int, bm25_mode: str = "forward"):
-        """K1 + K2 + metadata gather into the payload buffer of this rank."""
+    def local_scan(self, q_dev, pool_local: int):
+        """Phase 1 of K1 on this rank: the scan and this shard's bound per query (None: the call cannot be split)."""
+        kth = (pool_local + self.world - 1) // self.world        # the shards' kth best rows together: >= pool rows
+        return self.s.dense_scan(q_dev, pool_local, kth)
+
+    def local_payload(self, q_dev, term_id_lists, pool_local: int, bm25_mode: str = "forward", floor=None):
+        """K1 (+ the floor exchange when there is more than one shard) + K2 + metadata gather into the payload buffer of
+        this rank.  ``floor``: tests that play several shards in one process pass the minimum they formed themselves
+        (after calling local_scan on every shard); ``False`` = plain K1."""
         import torch
         s = self.s
         B = q_dev.shape[0]
         lay = PayloadLayout(B, pool_local)
         buf = torch.empty(lay.nbytes, dtype=torch.uint8, device=s.device)
         v = lay.views(buf)
-        s.dense_pool(q_dev, pool_local, out=(v["rows"], v["dense"]))   # K1 writes the payload in place
+        import torch.distributed as dist
+        if floor is None and self.world > 1 and self.use_floor and dist.is_available() and dist.is_initialized():
+            bound = self.local_scan(q_dev, pool_local)
+            # every rank takes the same branch: whether a call can be split depends on the batch and on the shard sizes
+            # only through properties all shards share (n_queries, pool; a shard too small for the filter path reports
+            # -inf bounds instead) -- a rank that could not split contributes -inf, i.e. no floor at all
+            mine = bound if bound is not None else torch.full((B,), float("-inf"), dtype=torch.float32, device=s.device)
+            floor = exchange_floor(mine, self.world, self.group)
+            if bound is None:
+                floor = False
+        if floor is None or floor is False:
+            s.dense_pool(q_dev, pool_local, out=(v["rows"], v["dense"]))   # K1 writes the payload in place
+        else:
+            s.dense_select(q_dev, pool_local, floor, out=(v["rows"], v["dense"]))
         s.bm25_at(term_id_lists, v["rows"], bm25_mode, out=v["bm25"])  # K2 too
         _lib.check(s.lib.rr_index_gather_meta_dev(
             s.index.handle, C.c_void_p(v["rows"].data_ptr()), B * pool_local,

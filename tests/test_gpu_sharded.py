@@ -159,3 +159,70 @@ def test_gate_and_rerank_columns_travel_through_the_payload_path():
     assert np.all(rr_col.max(axis=1) > 0.999) and np.all(rr_col.min(axis=1) == 0)   # min-max of the reranker scores
     no_gate = [t.cpu().numpy() for t in sh.search_batch_dev(q_dev, tl, k, w, rerank_k=rr_k, rerank_fn=rerank_fn)]
     assert not np.array_equal(no_gate[1][:, 7], a[1][:, 7])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_shards_select_against_a_corpus_wide_floor(dtype):
+    """Two-phase K1 of row shards (include/rr_hip.h: rr_dense_scan_dev / rr_dense_select_dev): every
+    shard scans and reports, per query, a lower bound of the score of its ceil(pool / shards)-th best row; the minimum over
+    the shards is a lower bound of the corpus-wide pool-th best score, and every shard then opens only what can reach it.
+    8 shards played in one process: the merged answer equals the unsharded one bit for bit, and the shards rescored a
+    fraction of the M-tiles their own thresholds would have opened."""
+    n, vocab, world, batch, k, pool = 640_000, 5000, 8, 256, 100, 150
+    V = synth.unit_rows(n, 384, 71)
+    n_rev, stars = synth.metadata(n, 72, nan_fraction=0.0)
+    ip, terms, tf, dl = synth.bm25_forward_csr(n, vocab, 20, 73)
+    corpus = BM25Corpus(ip, terms, tf, dl, vocab)
+    Q = synth.unit_rows(batch, 384, 74)
+    tl = synth.query_terms(batch, vocab, 75, np.bincount(terms, minlength=vocab))
+    w = FusionWeights(w_dense=0.5, w_bm25=0.5, w_rerank=0.0, w_prior=0.0, w_best=0.0, gate_penalty=1.0)
+
+    def build_t(lo, hi):
+        ix = ProductIndex.from_rows(V[lo:hi], row_offset=lo, dtype=dtype)
+        ix.set_meta(n_rev[lo:hi].astype(np.float64), stars[lo:hi])
+        return HybridSearcher(ix, corpus.slice(lo, hi).to_device(row_offset=lo))
+
+    q_dev = torch.from_numpy(Q).cuda()
+    whole = ShardedSearcher(build_t(0, n), n, 0, 1)
+    want = [t.cpu().numpy() for t in whole.search_batch_dev(q_dev, tl, k, w)]
+    shards = [ShardedSearcher(build_t(*shard_bounds(n, world, r)), n, r, world) for r in range(world)]
+    # plain per-shard selection first: how many M-tiles each shard opens on its own threshold
+    own = []
+    for sh in shards:
+        sh.local_payload(q_dev, tl, pool, floor=False)
+        torch.cuda.synchronize()
+        own.append(sh.s.index.select_trace()[2])
+    bounds = [sh.local_scan(q_dev, pool) for sh in shards]
+    assert all(b is not None for b in bounds), "a 256-query batch on an 80 000-row shard takes the filter path"
+    floor = torch.stack(bounds).min(dim=0).values
+    assert torch.isfinite(floor).all()
+    lay = PayloadLayout(batch, pool)
+    gathered = torch.empty((world, lay.nbytes), dtype=torch.uint8, device="cuda")
+    opened = []
+    for r, sh in enumerate(shards):
+        _, buf = sh.local_payload(q_dev, tl, pool, floor=floor)
+        gathered[r].copy_(buf)
+        torch.cuda.synchronize()
+        assert sh.s.index.select_trace()[0] == 2
+        opened.append(sh.s.index.select_trace()[2])
+    assert sum(opened) * 3 < sum(own), (opened, own)              # (query 0's M-tile lists: ~1/8 expected)
+    s0 = shards[0].s
+    params = HybridSearcher.make_params(w, k, pool, world * pool, 0, cand_per_rank=pool, stride_bytes=lay.nbytes)
+    out_rows = torch.empty((batch, pool), dtype=torch.int64, device="cuda")
+    cols = torch.empty((batch, 8, pool), dtype=torch.float64, device="cuda")
+    order = torch.empty((batch, k), dtype=torch.int32, device="cuda")
+    base = gathered.data_ptr()
+    p = lambda off: C.c_void_p(base + off)
+    _lib.check(s0.lib.rr_fuse_topk_dev(
+        s0.index.handle, C.byref(params), batch, p(lay.off_rows), p(lay.off_dense), p(lay.off_bm25),
+        p(lay.off_n), p(lay.off_avg), p(lay.off_l1p), None, None, None, C.c_void_p(out_rows.data_ptr()),
+        C.c_void_p(cols.data_ptr()), C.c_void_p(order.data_ptr()), s0._stream()), "rr_fuse_topk_dev")
+    torch.cuda.synchronize()
+    assert np.array_equal(out_rows.cpu().numpy(), want[0])
+    assert np.array_equal(cols.cpu().numpy(), want[1], equal_nan=True)
+    assert np.array_equal(order.cpu().numpy(), want[2])
+    # a phase 2 without its phase 1 is an error, and a plain search in between voids the parked scan
+    shards[0].local_scan(q_dev, pool)
+    shards[0].s.dense_pool(q_dev[:3], pool)
+    with pytest.raises(Exception):
+        shards[0].s.dense_select(q_dev, pool, floor)

@@ -145,3 +145,28 @@ def test_rerank_flow_two_collectives_config5(n_pairs):
     for w_ in (1, 3, 8):
         cover = [split_pairs(n_pairs, w_, r) for r in range(w_)]
         assert cover[0][0] == 0 and cover[-1][1] == n_pairs and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+
+
+def _floor_worker(rank, world, port, ret):
+    from review_recommender_amd.sharded import exchange_floor
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # per-query bounds of this "shard": rank 1 could not split its call for query 2 (-inf = no floor for it)
+        mine = torch.tensor([0.30 + 0.01 * rank, 0.25 - 0.02 * rank, float("-inf") if rank == 1 else 0.4], dtype=torch.float32)
+        ret[rank] = exchange_floor(mine, world).numpy().copy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_floor_exchange_is_the_elementwise_minimum():
+    """The collective in front of the shards' selection (two-phase K1): every rank ends with the
+    per-query minimum of the shards' bounds; one -inf makes the floor -inf (that query is selected as if unsharded)."""
+    world = 2
+    port = free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_floor_worker, args=(world, port, ret), nprocs=world, join=True)
+    want = np.array([0.30, 0.23, -np.inf], dtype=np.float32)
+    for r in range(world):
+        assert np.array_equal(ret[r], want)
