@@ -483,7 +483,7 @@ def main():
                                        f"postings per query)" if not args.no_bm25 else "")
                                     + f", batches of {args.batch} queries"),
                        "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k,
-                       "pool": pool, "parallelism": f"row-shard x{world} + 1 all-reduce(min, B floats) + 1 all-gather"},
+                       "pool": pool, "parallelism": f"row-shard x{world}" + (" + 1 all-reduce(min, B floats)" if world > 1 else "") + " + 1 all-gather"},
             "roofline": roof,
             # the single-query scan on the same shard: the HBM-bound end of the same path
             "roofline_single_query": single,
