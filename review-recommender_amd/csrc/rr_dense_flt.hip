@@ -36,26 +36,21 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define RR_FLT_QSTRIDE 49   // 16-B units per query in LDS: 48 + 1 pad (eight consecutive queries, eight bank groups)
 
-// One workgroup (64 lanes) per query slot: the bf16 plane (round to nearest even) in the k order the
-// scan's A fragments imply, and the slot's error bound (see rr_flt_bounds).
+// One workgroup (64 lanes) per query slot: the bf16 plane (round to nearest even, memory order: both filter scans take
+// their A operands as they sit in the rows) and the slot's error bound (see rr_flt_bounds).
 struct rr_flt_bounds {
     float row_norm;      // >= max over rows ||a||
     float row_delta;     // >= max over rows ||a - bf16(a)||   (0 for a bf16 matrix)
 };
 __global__ __launch_bounds__(64) void rr_flt_prep_queries(const float* __restrict__ q, unsigned short* __restrict__ plane,
-                                                          float* __restrict__ eps, rr_flt_bounds B, int order) {
+                                                          float* __restrict__ eps, rr_flt_bounds B) {
     const int slot = blockIdx.x, lane = threadIdx.x;
     const float* src = q + (int64_t)slot * 384;
     float ss = 0.f, sr = 0.f, sd = 0.f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int pos = lane + 64 * i;
-        int from = pos;
-        if (order == RR_X3_ORDER_WIDE_BF16) {
-            const int e = pos & 31, v = e >> 4, h = (e >> 3) & 1, j = e & 7;
-            from = (pos & ~31) + 16 * h + 8 * v + j;
-        }
-        const float x = src[from];
+        const float x = src[pos];
         const __bf16 r = (__bf16)x;                                // round to nearest even
         const float xr = (float)r, d = x - xr;
         ss = __builtin_fmaf(x, x, ss);
@@ -140,8 +135,7 @@ __device__ __forceinline__ uint32_t rr_cvt_u32_sat(float x) {
     return r;
 }
 // rr_scan_flt below is the scan of FP32 rows (an fp32 index without its bf16 filter plane: RR_NO_SHADOW=1, or no room
-// for the plane); a bf16 stream -- the plane, or a bf16 matrix -- is scanned by rr_scan_flt16 further down and the
-// A_BF16 = true side of this template is no longer instantiated.
+// for the plane); a bf16 stream -- the plane, or a bf16 matrix -- is scanned by rr_scan_flt16 further down.
 // RR_FLT_THREADS(NQ2): workgroup size.  Four query tiles want 270 registers for a B-fragment lead of two
 // K-steps; RR_FLT_ONE_WAVE=1 builds that variant (one wave per SIMD, the whole register file, lead 2):
 // measured equal to two waves per SIMD with lead 1 (scan(128 q) / scan(32 q) = 1.14 either way), so off.
@@ -151,7 +145,7 @@ __device__ __forceinline__ uint32_t rr_cvt_u32_sat(float x) {
 #endif
 // DBG != 0: timing-only ablations (rr_debug_scan_flt, tools/flt_ablate.py; wrong results): bit 0 no epilogue
 // (accumulators kept alive), bit 1 no B-fragment reads, bit 2 no MFMAs, bit 3 no lane swaps / conversions, bit 4 no M-tile maxima stores.
-template <int NQ2, bool A_BF16, int DBG = 0>
+template <int NQ2, int DBG = 0>
 __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 1 : 2)) void rr_scan_flt(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [32*NQ2][48] units
     float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq,
@@ -159,9 +153,9 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     uint32_t* __restrict__ dummy) {       // [n_waves][32*NQ2] lines that absorb the skipped stores
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
-    constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
-    constexpr int SEGS = A_BF16 ? 1 : 2;              // ring segments (24 units per lane) per 32-row M-tile
-    constexpr int STEPS = A_BF16 ? 24 : 12;           // K-steps (16 dims) per ring segment
+    constexpr int ROWU = 96;                          // 16-byte units per fp32 matrix row
+    constexpr int SEGS = 2;                           // ring segments (24 units per lane) per 32-row M-tile
+    constexpr int STEPS = 12;                         // K-steps (16 dims) per ring segment
     __shared__ u32x4 qs[QN * RR_FLT_QSTRIDE];
     __shared__ float sg[QN];
     const int tid = threadIdx.x;
@@ -229,7 +223,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
     };
     // ---- software pipeline (see rr_dense_x3w.hip): during the NQ2 MFMAs of K-step s the vector issue
     // prepares K-step s + 1: 4 lane swaps + 4 packed conversions (fp32 matrix) and NQ2 ds_reads.
-    constexpr int NV = A_BF16 ? 4 : 8;
+    constexpr int NV = 8;
     constexpr int VPS = (NV + NQ2 - 1) / NQ2;
     u32x4 lo, hi, nxt;             // the pair being prepared (MFMA lanes) and its bf16 operand
     bf16x8 af;                     // operand of the current K-step
@@ -239,14 +233,14 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
             const auto r = __builtin_amdgcn_permlane16_swap(x[k], y[k], false, false);
             lo[k] = r[0];
             hi[k] = r[1];
-        } else if (!A_BF16 && k < 8) {
+        } else if (k < 8) {
             cvt_op(k - 4, lo, hi, nxt);
         }
     };
     {   // prologue: K-step 0 of the first segment
 #pragma unroll
         for (int k = 0; k < 8; ++k) valu_op(k, a[0], a[1]);
-        af = __builtin_bit_cast(bf16x8, A_BF16 ? lo : nxt);
+        af = __builtin_bit_cast(bf16x8, nxt);
 #pragma unroll
         for (int t = 0; t < NQ2; ++t) {
             qf[0][t] = read_q(t, 0);
@@ -269,11 +263,11 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                 const int cb = (p * STEPS + s) & 1;
                 const int s2 = (s + 1) % STEPS;                           // the K-step being prepared
                 constexpr int LEAD = (NQ2 >= 4 && THREADS == 512) ? 1 : 2;   // K-steps of B-fragment prefetch (4 tiles x 2 waves/SIMD: no registers for 2)
-                const int kk3 = A_BF16 ? (s + LEAD) % 24 : (12 * p + s + LEAD) % 24;   // K-step of the row LEAD steps ahead
-                const bool swap = A_BF16 ? (s2 % 2 == 0) : true;          // it starts a new pair of the ring
-                const int np = A_BF16 ? s2 / 2 : s2;
+                const int kk3 = (12 * p + s + LEAD) % 24;                 // K-step of the row LEAD steps ahead
+                const bool swap = true;                                   // every K-step starts a new pair of the ring
+                const int np = s2;
                 constexpr int REFILL_SLOT = 3 / VPS;                      // the slot that issues the last lane swap
-                constexpr int STORE_STEP = A_BF16 ? 10 : 5;               // the K-step after the first burst (np == 5)
+                constexpr int STORE_STEP = 5;                             // the K-step after the first burst (np == 5)
                 if (swap && (np == 6 || np == 0)) {
                     // ring waits and deferred maxima stores exactly as in rr_scan_x3w
                     // (younger than what the wait needs: the other half's burst, and for the segment's second wait
@@ -326,8 +320,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (A_BF16) af = __builtin_bit_cast(bf16x8, (s2 % 2 == 0) ? lo : hi);
-                else af = __builtin_bit_cast(bf16x8, nxt);
+                af = __builtin_bit_cast(bf16x8, nxt);
             }
         }
         if (DBG & 1) {
@@ -409,7 +402,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
 
 // ------------------------------------------------------------------ the filter scan over a bf16 stream: 16x16x32 tiles
 // The scan of a bf16 matrix / of the bf16 filter plane (rr_scan_flt above stays the scan of fp32 rows).  Same stream,
-// same tile words, same bound; what differs is the matrix-core tiling.  In-kernel stamps on rr_scan_flt<4, bf16> showed
+// same tile words, same bound; what differs is the matrix-core tiling.  In-kernel stamps on the 32x32x16 tiling of this stream (round 2's first) showed
 // the K-loop, not HBM, pacing the two-set launch: a wave alone on its SIMD needed 45 cycles per 32-cycle MFMA, two
 // waves together no less -- the four v_permlane16_swap per 64 bytes of a row (the 32x32x16 A operand wants lane (row c,
 // k half h), the coalesced loads deliver (row l & 15, 16-byte piece l >> 4)) sit on the vector issue between the MFMAs.
@@ -866,14 +859,14 @@ static int rr_flt_get_bounds(rr_index* ix, hipStream_t st, rr_flt_bounds* out) {
     return RR_OK;
 }
 
-// dual: the geometry of a two-set launch (rr_scan_flt<.., DUAL>): half the resident waves per set, runs twice as long,
+// dual: the geometry of a two-set launch (rr_scan_flt16<.., DUAL>): half the resident waves per set, runs twice as long,
 // eighth runs as selection groups (the same number and size of groups as a single-set launch)
 template <int NQ2, bool A_BF16>
 static rr_scan_geom rr_flt_geom(rr_index* ix, bool dual = false) {
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     static int waves = 0;
     if (!waves) waves = A_BF16 ? rr_resident_waves((const void*)rr_scan_flt16<NQ2>, 512, ix->device)
-                               : rr_resident_waves((const void*)rr_scan_flt<NQ2, false>, THREADS, ix->device);
+                               : rr_resident_waves((const void*)rr_scan_flt<NQ2>, THREADS, ix->device);
     rr_scan_geom G = rr_make_geom(ix, dual ? waves / 8 : waves / 4);
     G.qs = 32 * NQ2;
     G.mm_pairs = 3;
@@ -941,8 +934,7 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
     float* eps = X.eps + set * RR_FLT_MAXQ;
     float* gmax = ix->d_gmax + set * rr_flt_mmax_set_stride(G);
     uint32_t* smax = ix->d_smax + set * rr_flt_smax_set_stride();
-    hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, eps, bounds,
-                       RR_X3_ORDER_NATURAL);         // (both scans take their A operands in memory order)
+    hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, eps, bounds);   // (planes in memory order)
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     // Store prefilter (bf16 stream, >= 2M rows): a 1/64 tile sample gives every query sigma = its m-th largest sampled
     // tile maximum - 2.05 eps.  The m-th largest of a 1/stride sample sits near rank m * stride of all rows; m leaves the
@@ -982,7 +974,7 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
                            reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy, 0, (int64_t)0,
                            (uint32_t*)nullptr, 0u, rr_flt_tune());
     else
-        hipLaunchKernelGGL((rr_scan_flt<NQ2, false>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+        hipLaunchKernelGGL((rr_scan_flt<NQ2>), grid, block, 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
                            reinterpret_cast<const u32x4*>(plane), gmax, smax, eps, nq, sigma, dummy);
     rr_scan_events_end(ix, slot, st);
     RR_HIP_TRY(hipGetLastError());
@@ -1061,7 +1053,7 @@ template <bool SCAN_BF16, bool ROWS_BF16>
 static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* d_q, int nq_a, int nq_b, int pool,
                                int64_t* d_rows, float* d_scores, rr_flt_bounds bounds, hipStream_t st,
                                const rr_flt_phase& ph = rr_flt_phase()) {
-    // bf16 stream: both sets in ONE launch, the matrix leaves HBM once for the 256 queries (rr_scan_flt<.., DUAL>).
+    // bf16 stream: both sets in ONE launch, the matrix leaves HBM once for the 256 queries (rr_scan_flt16<.., DUAL>).
     // RR_NO_DUAL=1: two launches back to back (A/B).  An fp32 stream (no plane) keeps the two launches: its ring is
     // two segments per M-tile and the pair's lock-step window would be twice as wide.
     static const bool no_dual = getenv("RR_NO_DUAL") != nullptr;
@@ -1185,7 +1177,7 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
                                (const float*)nullptr, (uint32_t*)nullptr, 0, (int64_t)0, reinterpret_cast<uint32_t*>(d_stamps), 0u,
                                rr_flt_tune());
         else
-            hipLaunchKernelGGL((rr_scan_flt<4, false, DBG>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
+            hipLaunchKernelGGL((rr_scan_flt<4, DBG>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
                                reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128,
                                (const float*)nullptr, (uint32_t*)nullptr);
         hipEventRecord(e1, st);
