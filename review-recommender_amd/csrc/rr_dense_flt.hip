@@ -512,7 +512,8 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
     const uint64_t dbg_r0 = (DBG & 128) ? __builtin_amdgcn_s_memrealtime() : 0;
 #pragma unroll 1
     for (int64_t mt = m0; mt < m1; ++mt) {
-        // The MFMAs are spelled out (accumulating in place, the first K-step with a literal zero C): left to the
+        // The MFMAs are spelled out (accumulating in place, the first K-step with a literal zero C and an early-clobber
+        // destination: it must not land on a source operand that dies there): left to the
         // register allocator the unrolled chain took a fresh destination per MFMA, 256 registers and 49-86 spills,
         // whose reloads (vmcnt(0)) sat in the K-loop.  The compiler still sees every operand (it places the lgkmcnt
         // waits for the B fragments); what it cannot see is the MFMA -> VALU distance: see the s_nop behind the K-loop.
@@ -536,8 +537,8 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 if (ks == 0) {
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[0][f]) : "v"(a0), "v"(qf[f]));
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[1][f]) : "v"(a1), "v"(qf[f]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[0][f]) : "v"(a0), "v"(qf[f]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[1][f]) : "v"(a1), "v"(qf[f]));
                 } else {
                     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[0][f]) : "v"(a0), "v"(qf[f]));
                     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[1][f]) : "v"(a1), "v"(qf[f]));
@@ -683,6 +684,187 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
         for (int t = 0; t < NQ2; ++t) {
             if (!my_dummy || ((pend_keep >> t) & 1u)) reinterpret_cast<uint32_t*>(gmax)[(m1 - 1) * QN + 32 * t + c] = pend[t];
         }
+    }
+}
+
+// ------------------------------------------------------------------ the two-set scan, query-stationary
+// rr_scan_flt16 keeps the QUERIES in LDS and streams the rows through registers: every wave loads its own rows, 24
+// fragment-shaped global_load_dwordx4 (16 rows x 64 B each) per 32-row M-tile and 128 queries, and the issue of those
+// loads is serial with the MFMAs of the SIMD (~60 cycles each beside 3 072 cycles of MFMA: DESIGN.md section 8).  Here
+// the roles are swapped for the 256-query launch:
+//   * one workgroup per CU, FOUR waves (one per SIMD, 512 registers each); wave w owns queries 64 w .. 64 w + 63 of the
+//     launch's 256 (waves 0, 1 = set 0; 2, 3 = set 1) and keeps their B fragments -- 4 fragments x 12 K-steps x 4
+//     registers = 192 -- in ACCUMULATION registers for the whole launch: no LDS planes at all;
+//   * the ROWS come through LDS, once per CU: a 32-row M-tile = 24 LDS-DMA pieces (global_load_lds_dwordx4) of 8 rows x
+//     128 B -- whole lines, half the address-path cost of fragment-shaped loads --, six per wave, three M-tiles ahead in
+//     a ring of four 24 KB buffers; all four waves read their A operands from that one image (ds_read_b128, one per 4
+//     MFMAs, conflict-free: a piece is stored 16-byte-swizzled by (row & 7) through its SOURCE addresses);
+//   * so the stream leaves HBM once for 256 queries without any pairing of workgroups, and a row costs a quarter of the
+//     vector-memory issue per query it did.
+// Per M-tile and wave: 96 MFMAs (16x16x32), 24 ds_read_b128, 6 LDS-DMA pieces, one raw s_barrier, the epilogue of its
+// 64 queries (two 32-query blocks, as in rr_scan_flt16) and two tile-word stores.  Runs: one per workgroup (G.n_waves =
+// number of runs), groups = 1/32 of a run.
+template <int DBG = 0>
+__global__ __launch_bounds__(256, 1) void rr_scan_fltq(
+    const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [256][48] units: set 0, then set 1
+    float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq_a, int nq_b,
+    int64_t gmax_set_stride) {
+    constexpr int NB = 4;                             // ring of M-tile images
+    constexpr int TILE_UNITS = 32 * RR_X3_UNITS;      // 16-byte units per image (24 KB)
+    __shared__ u32x4 ring[NB * TILE_UNITS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int run = blockIdx.x;
+    if (run >= G.n_waves) return;                     // (whole workgroup)
+    const int set = w >> 1;
+    const int qoff = 64 * (w & 1);                    // this wave's first query inside its set
+    const int nq = set ? nq_b : nq_a;
+    float* const gm_out = gmax + set * gmax_set_stride;
+    uint32_t* const sm_out = smax + (size_t)set * RR_FLT_MAXQ * RR_MAX_SCAN_WAVES;
+    const float* const eps_set = eps + set * RR_FLT_MAXQ;
+    const int64_t t0 = (int64_t)run * G.tiles_per_wave;
+    const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
+    const int64_t m0 = t0 * 2, m1 = t1 * 2;           // 32-row M-tiles of this run
+
+    // ---- B fragments: query 16 f + (l & 15) of this wave, dims 32 ks + 8 (l >> 4) .. + 7  ->  bq[ks][f], accumulation registers
+    u32x4 bq[12][4];
+    {
+        const u32x4* src = plane + ((size_t)(64 * w + (lane & 15)) * RR_X3_UNITS + (lane >> 4));
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[ks][f]) : "v"(src + (16 * f) * RR_X3_UNITS + 4 * ks) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) asm volatile("" : "+a"(bq[ks][f]));
+    }
+
+    // ---- LDS-DMA: wave w brings rows 8 w .. 8 w + 7 of an M-tile, segment j = bytes 128 j .. 128 j + 127 of each row;
+    // lane l = (row l >> 3, slot l & 7) fetches piece (slot ^ row) so that the linear image holds piece p of row r8 in
+    // slot p ^ r8 (bank-conflict-free A reads below)
+    const int d_r8 = lane >> 3, d_slot = lane & 7;
+    auto dma_tile = [&](int64_t mt, int buf) {
+        mt = mt < m1 ? mt : m1 - 1;                   // (past the end: redundant, never read)
+        if (DBG & 64) mt = m0 + (mt & 1);             // timing only: cache hits
+        int64_t row = mt * 32 + 8 * w + d_r8;
+        row = row < G.n_rows ? row : G.n_rows - 1;
+        const u32x4* src = mat + row * RR_X3_UNITS + (d_slot ^ d_r8);
+        u32x4* dst = ring + buf * TILE_UNITS + (w * 6) * 64;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            __builtin_amdgcn_global_load_lds(src + 8 * j, (__attribute__((address_space(3))) void*)(dst + j * 64), 16, 0, 0);
+    };
+    // ---- A operand reads: lane (row rl = l & 15, k quarter l >> 4) of row half hf, K-step ks:
+    //      unit = ((2 hf + (rl >> 3)) * 6 + (ks >> 1)) * 64 + (rl & 7) * 8 + ((4 (ks & 1) + quarter) ^ (rl & 7))
+    const int rl = lane & 15, quarter = lane >> 4, r8 = rl & 7;
+    const int a_base = ((rl >> 3) * 6) * 64 + r8 * 8;
+    const int a_x0 = quarter ^ r8, a_x1 = (4 + quarter) ^ r8;
+    // (ds_read_b128 spelled out with counted lgkmcnt waits: left to the compiler every third step waited for the read it
+    //  had just issued)
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring;
+    const uint32_t a_even = ring_lds + 16u * (uint32_t)(a_base + a_x0), a_odd = ring_lds + 16u * (uint32_t)(a_base + a_x1);
+#define RR_FLTQ_READ_A(dst, tile_even, tile_odd, i) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((((i) >> 1) & 1) ? (tile_odd) : (tile_even)), \
+                 "n"(16 * (((i) & 1) * (12 * 64) + ((i) >> 2) * 64)) : "memory")
+
+    const int c = lane & 31, h = lane >> 5;
+    const uint32_t code_shift = 16u + 4u * (uint32_t)h;
+    const float step = rr_flt_gap_step(eps_set, nq);
+    const float inv_step = step > 0.f ? 0.9999f / step : 0.f;
+    float gm[2] = {-INFINITY, -INFINITY};
+
+    dma_tile(m0, 0);
+    dma_tile(m0 + 1, 1);
+    dma_tile(m0 + 2, 2);
+#pragma unroll 1
+    for (int64_t mt = m0; mt < m1; ++mt) {
+        const int it = (int)(mt - m0), buf = it & (NB - 1);
+        // this wave's six pieces of M-tile mt have landed once at most the two younger M-tiles' pieces (12) and the tile-word
+        // stores issued since (2 per M-tile, 3 M-tiles) are outstanding; then all four waves' pieces have, behind the barrier
+        if (it < 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        dma_tile(mt + 3, (it + 3) & (NB - 1));        // its buffer held M-tile mt - 1: every wave is past reading it
+        f32x4 acc[2][4];
+        bf16x8 a[3];
+        const uint32_t te = a_even + (uint32_t)buf * (TILE_UNITS * 16), to = a_odd + (uint32_t)buf * (TILE_UNITS * 16);
+        RR_FLTQ_READ_A(a[0], te, to, 0);
+        RR_FLTQ_READ_A(a[1], te, to, 1);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {                    // step i = 2 ks + hf: row half hf of K-step ks
+            const int ks = i >> 1, hf = i & 1;
+            if (i + 2 < 24) {
+                RR_FLTQ_READ_A(a[(i + 2) % 3], te, to, i + 2);
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");      // reads return in order: step i's is in
+            } else if (i + 1 < 24) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(a[i % 3]));
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                if (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[hf][f]) : "v"(a[i % 3]), "a"(bq[ks][f]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[hf][f]) : "v"(a[i % 3]), "a"(bq[ks][f]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
+                     "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]) :: "memory");
+        // ---- epilogue: this wave's 64 queries = two 32-query blocks (see rr_scan_flt16 for the lane arrangement)
+        if (mt * 32 + 32 > G.n_rows) {
+            const int64_t rbase = mt * 32 + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[r][f] = rr_x3_canon(acc[r][f], rbase + 16 * r, G.n_rows);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float uw[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const f32x4 va = acc[r][2 * t], vb = acc[r][2 * t + 1];
+                const float x = rr_vmax3(va.x, va.y, rr_vmax(va.z, va.w)), y = rr_vmax3(vb.x, vb.y, rr_vmax(vb.z, vb.w));
+                const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                uw[r] = rr_vmax(__uint_as_float(rs[0]), __uint_as_float(rs[1]));
+            }
+            const float u = uw[0], wv = uw[1];
+            const float mh = rr_vmax(u, wv);
+            const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
+            const float m32 = rr_vmax(__uint_as_float(rm[0]), __uint_as_float(rm[1]));
+            gm[t] = rr_vmax(gm[t], m32);
+            const uint32_t b = __float_as_uint(m32);
+            uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);
+            const float gu = (m32 - u) * inv_step, gw = (m32 - wv) * inv_step;
+            uint32_t cu = rr_cvt_u32_sat(gu), cw = rr_cvt_u32_sat(gw);
+            cu = cu < 12u ? cu : 12u;
+            cw = cw < 12u ? cw : 12u;
+            cu += (gu >= 16.f ? 1u : 0u) + (gu >= 24.f ? 1u : 0u) + (gu >= 40.f ? 1u : 0u);
+            cw += (gw >= 16.f ? 1u : 0u) + (gw >= 24.f ? 1u : 0u) + (gw >= 40.f ? 1u : 0u);
+            const uint32_t mine = (cu | (cw << 8)) << code_shift;
+            const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+            word |= rc[0] | rc[1];
+            if (h == 0) reinterpret_cast<uint32_t*>(gm_out)[mt * RR_FLT_MAXQ + qoff + 32 * t + c] = word;
+        }
+        {
+            const int in_run = (int)((mt >> 1) - t0), cg = (int)G.tiles_per_group;
+            if ((mt & 1) == 1 && ((in_run + 1) % cg == 0 || mt == m1 - 1)) {
+                const int64_t group = (int64_t)run * G.gpw + in_run / cg;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (h == 0) sm_out[group * RR_FLT_MAXQ + qoff + 32 * t + c] = rr_f2key(gm[t]);
+                    gm[t] = -INFINITY;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) pieces
+    if (h == 0) {
+        const int cg = (int)G.tiles_per_group;
+        for (int k = (int)((t1 - t0 + cg - 1) / cg); k < G.gpw; ++k)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) sm_out[((int64_t)run * G.gpw + k) * RR_FLT_MAXQ + qoff + 32 * t + c] = 0u;
     }
 }
 
@@ -879,6 +1061,20 @@ static rr_scan_geom rr_flt_geom(rr_index* ix, bool dual = false) {
     return G;
 }
 
+// geometry of rr_scan_fltq: one run per resident workgroup (= CU), 32 selection groups per run
+static rr_scan_geom rr_fltq_geom(rr_index* ix) {
+    static int runs = 0;
+    if (!runs) runs = rr_resident_waves((const void*)rr_scan_fltq<0>, 256, ix->device) / 4;
+    rr_scan_geom G = rr_make_geom(ix, runs / 4);      // (rr_make_geom counts 4 "waves" per resident block)
+    G.qs = RR_FLT_MAXQ;
+    G.mm_pairs = 3;
+    G.gpw = RR_MAX_SCAN_WAVES / G.n_waves < 32 ? (RR_MAX_SCAN_WAVES / G.n_waves < 1 ? 1 : RR_MAX_SCAN_WAVES / G.n_waves) : 32;
+    if (G.gpw > G.tiles_per_wave) G.gpw = (int32_t)G.tiles_per_wave;
+    G.tiles_per_group = (G.tiles_per_wave + G.gpw - 1) / G.gpw;
+    G.gpw = (int32_t)((G.tiles_per_wave + G.tiles_per_group - 1) / G.tiles_per_group);
+    return G;
+}
+
 // fp32 rows -> the bf16 filter plane (round to nearest even, the rounding rr_row_norm_max<false> bounds)
 __global__ __launch_bounds__(256) void rr_shadow_from_f32(const f32x4* __restrict__ src, u32x2* __restrict__ dst, int64_t n4) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1058,7 +1254,10 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
     // two segments per M-tile and the pair's lock-step window would be twice as wide.
     static const bool no_dual = getenv("RR_NO_DUAL") != nullptr;
     const bool dual = SCAN_BF16 && !no_dual;
-    const rr_scan_geom G = rr_flt_geom<4, SCAN_BF16>(ix, dual);
+    // RR_FLT_Q=1: the query-stationary kernel for the two-set launch (rows through LDS once per CU)
+    static const bool use_q = getenv("RR_FLT_Q") != nullptr;
+    const bool fltq = dual && use_q;
+    const rr_scan_geom G = fltq ? rr_fltq_geom(ix) : rr_flt_geom<4, SCAN_BF16>(ix, dual);
     const float *sg0 = nullptr, *sg1 = nullptr;
     // The store prefilter pays where the scan is HBM-bound (one set per launch: 1.41 -> 1.31 ms for 0.06 ms of sample
     // and sigma).  The two-set launch is paced by the matrix side: there the skipped stores save 0.08 ms per launch and
@@ -1069,7 +1268,16 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
     if (rc != RR_OK) return rc;
     rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 1, G, scan_mat, d_q + (int64_t)nq_a * ix->dim_pad, nq_b, pool, bounds, st, &sg1, !dual, pre);
     if (rc != RR_OK) return rc;
-    if (dual) {
+    if (fltq) {
+        const rr_x3_scratch X = rr_x3_scratch_of(ix);
+        const int slot = rr_scan_events_begin(ix, st);
+        rr_scan_note(ix, 5, 9, nq_a + nq_b, 1, 2);
+        hipLaunchKernelGGL((rr_scan_fltq<0>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
+                           rr_flt_mmax_set_stride(G));
+        rr_scan_events_end(ix, slot, st);
+        RR_HIP_TRY(hipGetLastError());
+    } else if (dual) {
         constexpr int THREADS = RR_FLT_THREADS(4);
         const int nb = (G.n_waves + THREADS / 64 - 1) / (THREADS / 64);        // workgroups per set
         const dim3 grid(((nb + 7) / 8) * 16), block(THREADS);
