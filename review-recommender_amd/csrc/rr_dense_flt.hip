@@ -708,7 +708,7 @@ template <int DBG = 0>
 __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [256][48] units: set 0, then set 1
     float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq_a, int nq_b,
-    int64_t gmax_set_stride) {
+    int64_t gmax_set_stride, unsigned long long* __restrict__ stamps = nullptr) {      // stamps: DBG & 128, [run][wave][4]
     constexpr int NB = 4;                             // ring of M-tile images
     constexpr int TILE_UNITS = 32 * RR_X3_UNITS;      // 16-byte units per image (24 KB)
     __shared__ u32x4 ring[NB * TILE_UNITS];
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     // lane l = (row l >> 3, slot l & 7) fetches piece (slot ^ row) so that the linear image holds piece p of row r8 in
     // slot p ^ r8 (bank-conflict-free A reads below)
     const int d_r8 = lane >> 3, d_slot = lane & 7;
-    auto dma_tile = [&](int64_t mt, int buf) {
+    auto dma_tile = [&](int64_t mt, int buf, int j0 = 0, int j1 = 6) {      // pieces j0 .. j1 - 1 of the wave's six
         mt = mt < m1 ? mt : m1 - 1;                   // (past the end: redundant, never read)
         if (DBG & 64) mt = m0 + (mt & 1);             // timing only: cache hits
         int64_t row = mt * 32 + 8 * w + d_r8;
@@ -754,7 +754,8 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
         u32x4* dst = ring + buf * TILE_UNITS + (w * 6) * 64;
 #pragma unroll
         for (int j = 0; j < 6; ++j)
-            __builtin_amdgcn_global_load_lds(src + 8 * j, (__attribute__((address_space(3))) void*)(dst + j * 64), 16, 0, 0);
+            if (j >= j0 && j < j1)
+                __builtin_amdgcn_global_load_lds(src + 8 * j, (__attribute__((address_space(3))) void*)(dst + j * 64), 16, 0, 0);
     };
     // ---- A operand reads: lane (row rl = l & 15, k quarter l >> 4) of row half hf, K-step ks:
     //      unit = ((2 hf + (rl >> 3)) * 6 + (ks >> 1)) * 64 + (rl & 7) * 8 + ((4 (ks & 1) + quarter) ^ (rl & 7))
@@ -774,92 +775,173 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     const float step = rr_flt_gap_step(eps_set, nq);
     const float inv_step = step > 0.f ? 0.9999f / step : 0.f;
     float gm[2] = {-INFINITY, -INFINITY};
+    f32x4 acc[2][2][4];                               // [set P = M-tile parity][row half][fragment]
 
+    // ---- the epilogue of one M-tile for this wave's 64 queries: block t = queries 32 t .. 32 t + 31, twelve pieces each.
+    // Piece (t, k) runs behind the MFMAs of step 12 t + k of the NEXT M-tile, on the accumulator set that M-tile does not
+    // write: in-kernel stamps had the epilogue + LDS-DMA issue at 1 350 of the 3 200 cycles of an M-tile with nothing on
+    // the matrix pipe; a handful of vector instructions per MFMA group issue in its shadow.
+    float ex0[2], ey0[2], eu[2], ew[2], em32[2], egu[2], egw[2];
+    uint32_t ecu[2], ecw[2], eword[2];
+    // (`live` = there is a previous M-tile: in a run's first body the pieces run on zeros and only their two effects --
+    //  the group maximum and the store -- are switched off; a branch around every piece cost more than the pieces)
+    auto piece = [&](int P, int t, int k, int half, int64_t tile, bool live) {      // (P, t, k, half: constants once unrolled)
+        // every piece in two halves of at most three vector instructions: a 16-cycle MFMA leaves the vector issue 8 cycles
+        if (k == 0 || k == 2) {
+            const int r = k / 2;
+            const f32x4 v = acc[P][r][2 * t + half];
+            (half ? ey0[t] : ex0[t]) = rr_vmax3(v.x, v.y, rr_vmax(v.z, v.w));
+        } else if (k == 1 || k == 3) {
+            if (half == 0) {
+                const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(ex0[t]), __float_as_uint(ey0[t]), false, false);
+                ex0[t] = __uint_as_float(rs[0]);
+                ey0[t] = __uint_as_float(rs[1]);
+            } else {
+                const float v = rr_vmax(ex0[t], ey0[t]);
+                if (k == 1) eu[t] = v;
+                else ew[t] = v;
+            }
+        } else if (k == 4) {
+            if (half == 0) {
+                const float mh = rr_vmax(eu[t], ew[t]);
+                const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
+                ex0[t] = __uint_as_float(rm[0]);
+                ey0[t] = __uint_as_float(rm[1]);
+            } else {
+                em32[t] = rr_vmax(ex0[t], ey0[t]);
+                gm[t] = live ? rr_vmax(gm[t], em32[t]) : gm[t];
+            }
+        } else if (k == 5) {
+            if (half == 0) {
+                const uint32_t b = __float_as_uint(em32[t]);
+                eword[t] = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);
+            }
+        } else if (k == 6) {
+            if (half == 0) egu[t] = (em32[t] - eu[t]) * inv_step;
+            else egw[t] = (em32[t] - ew[t]) * inv_step;
+        } else if (k == 7) {
+            if (half == 0) {
+                const uint32_t cu = rr_cvt_u32_sat(egu[t]);
+                ecu[t] = cu < 12u ? cu : 12u;
+            } else {
+                const uint32_t cw = rr_cvt_u32_sat(egw[t]);
+                ecw[t] = cw < 12u ? cw : 12u;
+            }
+        } else if (k == 8) {
+            if (half == 0) ecu[t] += (egu[t] >= 16.f ? 1u : 0u) + (egu[t] >= 24.f ? 1u : 0u);
+            else ecu[t] += (egu[t] >= 40.f ? 1u : 0u);
+        } else if (k == 9) {
+            if (half == 0) ecw[t] += (egw[t] >= 16.f ? 1u : 0u) + (egw[t] >= 24.f ? 1u : 0u);
+            else ecw[t] += (egw[t] >= 40.f ? 1u : 0u);
+        } else if (k == 10) {
+            if (half == 0) {
+                const uint32_t mine = (ecu[t] | (ecw[t] << 8)) << code_shift;
+                const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+                ecu[t] = rc[0];
+                ecw[t] = rc[1];
+            } else eword[t] |= ecu[t] | ecw[t];
+        } else if (k == 11) {
+            if (half == 1 && h == 0 && live)
+                reinterpret_cast<uint32_t*>(gm_out)[tile * RR_FLT_MAXQ + qoff + 32 * t + c] = eword[t];   // ONE store
+        }
+    };
+    auto finish_tile = [&](int64_t pm) {              // group bookkeeping of the M-tile whose epilogue has just finished
+        const int in_run = (int)((pm >> 1) - t0), cg = (int)G.tiles_per_group;
+        if ((pm & 1) == 1 && ((in_run + 1) % cg == 0 || pm == m1 - 1)) {
+            const int64_t group = (int64_t)run * G.gpw + in_run / cg;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (h == 0) sm_out[group * RR_FLT_MAXQ + qoff + 32 * t + c] = rr_f2key(gm[t]);
+                gm[t] = -INFINITY;
+            }
+        }
+    };
+    auto canon_set = [&](int P, int64_t tile) {       // rows past the end (and NaNs) of the matrix's last, short M-tile -> -inf
+        const int64_t rbase = tile * 32 + 4 * (lane >> 4);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[P][r][f] = rr_x3_canon(acc[P][r][f], rbase + 16 * r, G.n_rows);
+    };
+
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[1][r][f] = f32x4{0.f, 0.f, 0.f, 0.f};
     dma_tile(m0, 0);
     dma_tile(m0 + 1, 1);
     dma_tile(m0 + 2, 2);
-#pragma unroll 1
-    for (int64_t mt = m0; mt < m1; ++mt) {
+    uint64_t dbg_wait = 0, dbg_mfma = 0, dbg_epi = 0;
+    const uint64_t dbg_t0 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
+    constexpr int AD = 4;                             // A operands requested this many steps (4 MFMAs each) ahead
+    bf16x8 a[AD + 1];
+    auto body = [&](auto PC, int64_t mt) {
+        constexpr int P = decltype(PC)::value;        // accumulator set of THIS M-tile; 1 - P: the previous one's
         const int it = (int)(mt - m0), buf = it & (NB - 1);
-        // this wave's six pieces of M-tile mt have landed once at most the two younger M-tiles' pieces (12) and the tile-word
-        // stores issued since (2 per M-tile, 3 M-tiles) are outstanding; then all four waves' pieces have, behind the barrier
+        const bool have_prev = it > 0;
+        const uint64_t ts0 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
+        // this wave's six pieces of M-tile mt have landed once at most the two younger M-tiles' pieces (12) and the four
+        // word stores issued with them are outstanding; then all four waves' pieces have, behind the barrier -- which also
+        // says that every wave is done reading M-tile mt - 1
         if (it < 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        dma_tile(mt + 3, (it + 3) & (NB - 1));        // its buffer held M-tile mt - 1: every wave is past reading it
-        f32x4 acc[2][4];
-        bf16x8 a[3];
+        const uint64_t ts1 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
+        if (have_prev && (mt - 1) * 32 + 32 > G.n_rows) canon_set(1 - P, mt - 1);
         const uint32_t te = a_even + (uint32_t)buf * (TILE_UNITS * 16), to = a_odd + (uint32_t)buf * (TILE_UNITS * 16);
-        RR_FLTQ_READ_A(a[0], te, to, 0);
-        RR_FLTQ_READ_A(a[1], te, to, 1);
 #pragma unroll
-        for (int i = 0; i < 24; ++i) {                    // step i = 2 ks + hf: row half hf of K-step ks
+        for (int i = 0; i < AD; ++i) RR_FLTQ_READ_A(a[i], te, to, i);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {                // step i = 2 ks + hf: row half hf of K-step ks
             const int ks = i >> 1, hf = i & 1;
-            if (i + 2 < 24) {
-                RR_FLTQ_READ_A(a[(i + 2) % 3], te, to, i + 2);
-                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");      // reads return in order: step i's is in
-            } else if (i + 1 < 24) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+            if (i + AD < 24) RR_FLTQ_READ_A(a[(i + AD) % (AD + 1)], te, to, i + AD);
+            // reads return in order: with the (up to AD) younger ones outstanding, step i's is in
+            if (i + AD < 24) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(AD) : "memory");
+            else if (23 - i == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            else if (23 - i == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else if (23 - i == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(a[i % 3]));
+            asm volatile("" : "+v"(a[i % (AD + 1)]));
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                if (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[hf][f]) : "v"(a[i % 3]), "a"(bq[ks][f]));
-                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[hf][f]) : "v"(a[i % 3]), "a"(bq[ks][f]));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
-                     "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]) :: "memory");
-        // ---- epilogue: this wave's 64 queries = two 32-query blocks (see rr_scan_flt16 for the lane arrangement)
-        if (mt * 32 + 32 > G.n_rows) {
-            const int64_t rbase = mt * 32 + 4 * (lane >> 4);
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) acc[r][f] = rr_x3_canon(acc[r][f], rbase + 16 * r, G.n_rows);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float uw[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const f32x4 va = acc[r][2 * t], vb = acc[r][2 * t + 1];
-                const float x = rr_vmax3(va.x, va.y, rr_vmax(va.z, va.w)), y = rr_vmax3(vb.x, vb.y, rr_vmax(vb.z, vb.w));
-                const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-                uw[r] = rr_vmax(__uint_as_float(rs[0]), __uint_as_float(rs[1]));
-            }
-            const float u = uw[0], wv = uw[1];
-            const float mh = rr_vmax(u, wv);
-            const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
-            const float m32 = rr_vmax(__uint_as_float(rm[0]), __uint_as_float(rm[1]));
-            gm[t] = rr_vmax(gm[t], m32);
-            const uint32_t b = __float_as_uint(m32);
-            uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);
-            const float gu = (m32 - u) * inv_step, gw = (m32 - wv) * inv_step;
-            uint32_t cu = rr_cvt_u32_sat(gu), cw = rr_cvt_u32_sat(gw);
-            cu = cu < 12u ? cu : 12u;
-            cw = cw < 12u ? cw : 12u;
-            cu += (gu >= 16.f ? 1u : 0u) + (gu >= 24.f ? 1u : 0u) + (gu >= 40.f ? 1u : 0u);
-            cw += (gw >= 16.f ? 1u : 0u) + (gw >= 24.f ? 1u : 0u) + (gw >= 40.f ? 1u : 0u);
-            const uint32_t mine = (cu | (cw << 8)) << code_shift;
-            const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
-            word |= rc[0] | rc[1];
-            if (h == 0) reinterpret_cast<uint32_t*>(gm_out)[mt * RR_FLT_MAXQ + qoff + 32 * t + c] = word;
-        }
-        {
-            const int in_run = (int)((mt >> 1) - t0), cg = (int)G.tiles_per_group;
-            if ((mt & 1) == 1 && ((in_run + 1) % cg == 0 || mt == m1 - 1)) {
-                const int64_t group = (int64_t)run * G.gpw + in_run / cg;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    if (h == 0) sm_out[group * RR_FLT_MAXQ + qoff + 32 * t + c] = rr_f2key(gm[t]);
-                    gm[t] = -INFINITY;
+                if (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[P][hf][f]) : "v"(a[i % (AD + 1)]), "a"(bq[ks][f]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[P][hf][f]) : "v"(a[i % (AD + 1)]), "a"(bq[ks][f]));
+                if (f & 1) {
+                    piece(1 - P, i / 12, i % 12, f >> 1, mt - 1, have_prev);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        const uint64_t ts2 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
+        // the wave's six pieces of the M-tile three ahead (the buffer held M-tile mt - 1: read out, see the barrier)
+        dma_tile(mt + 3, (it + 3) & (NB - 1));
+        if (have_prev) finish_tile(mt - 1);
+        if (DBG & 128) {
+            const uint64_t ts3 = __builtin_amdgcn_s_memtime();
+            dbg_wait += ts1 - ts0; dbg_mfma += ts2 - ts1; dbg_epi += ts3 - ts2;
+        }
+    };
+    for (int64_t mt = m0; mt < m1; mt += 2) {
+        body(std::integral_constant<int, 0>{}, mt);
+        body(std::integral_constant<int, 1>{}, mt + 1);
     }
+    // tail: the last M-tile (set 1) has its epilogue to run
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0][0]), "+v"(acc[1][0][1]), "+v"(acc[1][0][2]), "+v"(acc[1][0][3]),
+                 "+v"(acc[1][1][0]), "+v"(acc[1][1][1]), "+v"(acc[1][1][2]), "+v"(acc[1][1][3]) :: "memory");
+    if ((m1 - 1) * 32 + 32 > G.n_rows) canon_set(1, m1 - 1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            piece(1, t, k, 0, m1 - 1, true);
+            piece(1, t, k, 1, m1 - 1, true);
+        }
+    finish_tile(m1 - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) pieces
+    if ((DBG & 128) && stamps && lane == 0) {
+        unsigned long long* o = stamps + ((size_t)run * 4 + w) * 4;
+        o[0] = dbg_wait; o[1] = dbg_mfma; o[2] = dbg_epi; o[3] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    }
     if (h == 0) {
         const int cg = (int)G.tiles_per_group;
         for (int k = (int)((t1 - t0 + cg - 1) / cg); k < G.gpw; ++k)
@@ -1457,6 +1539,37 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
             break;
         // 400 / 401 / 402 (16x16x32 kernel only; wrong results): stamped, cached, without the B-fragment reads / without the
         // ring re-loads, waits and tile-word stores / without either = the bare MFMA chain + epilogue
+        case 600: {       // rr_scan_fltq stamped (a 256-query search must have run: planes of both sets, scratch)
+            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
+            const rr_scan_geom G = rr_fltq_geom(ix);
+            unsigned long long* d_st = nullptr;
+            RR_HIP_TRY(hipMalloc((void**)&d_st, sizeof(unsigned long long) * 16 * 1024));
+            RR_HIP_TRY(hipMemset(d_st, 0, sizeof(unsigned long long) * 16 * 1024));
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            float total = 0.f;
+            for (int r = 0; r < reps + 1; ++r) {
+                hipEventRecord(e0, st);
+                hipLaunchKernelGGL((rr_scan_fltq<128>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
+                                   reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128, 128,
+                                   rr_flt_mmax_set_stride(G), d_st);
+                hipEventRecord(e1, st);
+                hipEventSynchronize(e1);
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (r) total += ms;
+            }
+            std::vector<unsigned long long> hst((size_t)16 * G.n_waves);
+            hipMemcpy(hst.data(), d_st, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            hipFree(d_st); hipEventDestroy(e0); hipEventDestroy(e1);
+            double sum[4] = {0, 0, 0, 0};
+            for (size_t k = 0; k < hst.size(); ++k) sum[k & 3] += (double)hst[k];
+            const double tiles = (double)((G.n_rows + 31) / 32) * 4;       // every wave of a workgroup walks every M-tile of its run
+            fprintf(stderr, "[fltq stamps] per M-tile and wave, shader cycles: wait + barrier %.0f, MFMA loop %.0f, epilogue + DMA issue %.0f; "
+                            "tile loop per wave %.0f\n", sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / (4.0 * G.n_waves));
+            *out_ms = total / reps;
+            break;
+        }
         case 400:
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
             *out_ms = rr_debug_time_flt<192 | 2, true>(ix, st, reps);
