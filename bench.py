@@ -522,7 +522,8 @@ def _scan_info(index):
     kid, variant, qpl, terms, ebytes = out[0], out[1], out[2], out[3], out[4]
     name = _KERNELS.get(kid, "unknown").replace("NQ2", str(variant)).replace("NQT", str(variant)).replace("NB", str(variant))
     if kid == 5 and ebytes == 2:          # a bf16 stream is scanned on 16x16x32 tiles; variant 8 = one launch for two 128-query sets
-        name = "rr_scan_flt16<4, two query sets>" if variant == 8 else f"rr_scan_flt16<{variant}>"
+        name = ("rr_scan_fltq (two query sets, query-stationary)" if variant == 9 else
+                "rr_scan_flt16<4, two query sets>" if variant == 8 else f"rr_scan_flt16<{variant}>")
     stream = "bf16 rows" if index.dtype == "bf16" else ("bf16 filter plane of the fp32 rows" if ebytes == 2 else "fp32 rows")
     return {"kernel": f"{name} over {stream}", "queries_per_launch": int(qpl), "mfma_terms": int(terms),
             "elem_bytes": int(ebytes) or (2 if index.dtype == "bf16" else 4)}

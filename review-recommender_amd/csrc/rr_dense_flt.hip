@@ -725,124 +725,116 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
     const int64_t m0 = t0 * 2, m1 = t1 * 2;           // 32-row M-tiles of this run
 
-    // ---- B fragments: query 16 f + (l & 15) of this wave, dims 32 ks + 8 (l >> 4) .. + 7  ->  bq[ks][f], accumulation registers
-    u32x4 bq[12][4];
+    // ---- B fragments (v_mfma_f32_32x32x16_bf16: 32 queries x 16 dims): query 32 f + (l & 31) of this wave, dims 16 ks +
+    // 8 (l >> 5) .. + 7  ->  bq[ks][f], accumulation registers (2 x 24 x 4 = 192)
+    u32x4 bq[24][2];
     {
-        const u32x4* src = plane + ((size_t)(64 * w + (lane & 15)) * RR_X3_UNITS + (lane >> 4));
+        const u32x4* src = plane + ((size_t)(64 * w + (lane & 31)) * RR_X3_UNITS + (lane >> 5));
 #pragma unroll
-        for (int ks = 0; ks < 12; ++ks)
+        for (int ks = 0; ks < 24; ++ks)
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[ks][f]) : "v"(src + (16 * f) * RR_X3_UNITS + 4 * ks) : "memory");
+            for (int f = 0; f < 2; ++f)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[ks][f]) : "v"(src + (32 * f) * RR_X3_UNITS + 2 * ks) : "memory");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int ks = 0; ks < 12; ++ks)
+        for (int ks = 0; ks < 24; ++ks)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) asm volatile("" : "+a"(bq[ks][f]));
+            for (int f = 0; f < 2; ++f) asm volatile("" : "+a"(bq[ks][f]));
     }
 
     // ---- LDS-DMA: wave w brings rows 8 w .. 8 w + 7 of an M-tile, segment j = bytes 128 j .. 128 j + 127 of each row;
-    // lane l = (row l >> 3, slot l & 7) fetches piece (slot ^ row) so that the linear image holds piece p of row r8 in
-    // slot p ^ r8 (bank-conflict-free A reads below)
+    // lane l = (row r8 = l >> 3, slot l & 7) fetches piece (slot ^ r8 ^ (w >> 1)) so that the linear image holds piece p of
+    // row r8 of row group w in slot p ^ r8 ^ (w >> 1): the A reads below (32 rows x one 16-byte piece per half wave) then
+    // touch every bank group once per 16-lane access group
     const int d_r8 = lane >> 3, d_slot = lane & 7;
     auto dma_tile = [&](int64_t mt, int buf, int j0 = 0, int j1 = 6) {      // pieces j0 .. j1 - 1 of the wave's six
         mt = mt < m1 ? mt : m1 - 1;                   // (past the end: redundant, never read)
         if (DBG & 64) mt = m0 + (mt & 1);             // timing only: cache hits
         int64_t row = mt * 32 + 8 * w + d_r8;
         row = row < G.n_rows ? row : G.n_rows - 1;
-        const u32x4* src = mat + row * RR_X3_UNITS + (d_slot ^ d_r8);
+        const u32x4* src = mat + row * RR_X3_UNITS + (d_slot ^ d_r8 ^ (w >> 1));
         u32x4* dst = ring + buf * TILE_UNITS + (w * 6) * 64;
 #pragma unroll
         for (int j = 0; j < 6; ++j)
             if (j >= j0 && j < j1)
                 __builtin_amdgcn_global_load_lds(src + 8 * j, (__attribute__((address_space(3))) void*)(dst + j * 64), 16, 0, 0);
     };
-    // ---- A operand reads: lane (row rl = l & 15, k quarter l >> 4) of row half hf, K-step ks:
-    //      unit = ((2 hf + (rl >> 3)) * 6 + (ks >> 1)) * 64 + (rl & 7) * 8 + ((4 (ks & 1) + quarter) ^ (rl & 7))
-    const int rl = lane & 15, quarter = lane >> 4, r8 = rl & 7;
-    const int a_base = ((rl >> 3) * 6) * 64 + r8 * 8;
-    const int a_x0 = quarter ^ r8, a_x1 = (4 + quarter) ^ r8;
-    // (ds_read_b128 spelled out with counted lgkmcnt waits: left to the compiler every third step waited for the read it
-    //  had just issued)
+    // ---- A operand reads (32 rows x 16 dims): lane (row R = l & 31, k half l >> 5) of K-step ks wants piece P = 2 ks + (l >> 5):
+    //      unit = ((R >> 3) * 6 + (P >> 3)) * 64 + (R & 7) * 8 + ((P & 7) ^ (R & 7) ^ (R >> 4))
+    // (P & 7 = 2 (ks & 3) + k half: four per-lane addresses, one per ks & 3; P >> 3 = ks >> 2 goes into the offset field)
+    const int aR = lane & 31, aH = lane >> 5, ar8 = aR & 7;
+    const int a_base = ((aR >> 3) * 6) * 64 + ar8 * 8;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring;
-    const uint32_t a_even = ring_lds + 16u * (uint32_t)(a_base + a_x0), a_odd = ring_lds + 16u * (uint32_t)(a_base + a_x1);
-#define RR_FLTQ_READ_A(dst, tile_even, tile_odd, i) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"((((i) >> 1) & 1) ? (tile_odd) : (tile_even)), \
-                 "n"(16 * (((i) & 1) * (12 * 64) + ((i) >> 2) * 64)) : "memory")
-
+    uint32_t a_addr[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a_addr[m] = ring_lds + 16u * (uint32_t)(a_base + ((2 * m + aH) ^ ar8 ^ (aR >> 4)));
+#define RR_FLTQ_READ_A(dst, tile_off, ks) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a_addr[(ks) & 3] + (tile_off)), "n"(16 * (((ks) >> 2) * 64)) : "memory")
     const int c = lane & 31, h = lane >> 5;
     const uint32_t code_shift = 16u + 4u * (uint32_t)h;
     const float step = rr_flt_gap_step(eps_set, nq);
     const float inv_step = step > 0.f ? 0.9999f / step : 0.f;
     float gm[2] = {-INFINITY, -INFINITY};
-    f32x4 acc[2][2][4];                               // [set P = M-tile parity][row half][fragment]
+    f32x16 acc[2][2];                                 // [set P = M-tile parity][fragment of 32 queries]
 
-    // ---- the epilogue of one M-tile for this wave's 64 queries: block t = queries 32 t .. 32 t + 31, twelve pieces each.
-    // Piece (t, k) runs behind the MFMAs of step 12 t + k of the NEXT M-tile, on the accumulator set that M-tile does not
-    // write: in-kernel stamps had the epilogue + LDS-DMA issue at 1 350 of the 3 200 cycles of an M-tile with nothing on
-    // the matrix pipe; a handful of vector instructions per MFMA group issue in its shadow.
-    float ex0[2], ey0[2], eu[2], ew[2], em32[2], egu[2], egw[2];
+    // ---- the epilogue of one M-tile for this wave's 64 queries: block t = fragment t = queries 32 t .. 32 t + 31.
+    // C layout (lane (query c = l & 31, h = l >> 5), register 4 g + i): row 8 g + 4 h + i.  Pieces of at most three
+    // vector instructions, one behind every MFMA of the NEXT M-tile (a 32-cycle MFMA leaves the vector issue 24 cycles;
+    // with one wave per SIMD only what stands right behind an MFMA in program order issues in its shadow), on the
+    // accumulator set that M-tile does not write.  24 pieces per block: MFMA 2 ks + f of the next M-tile runs piece
+    // (t = its index / 24, k = its index % 24).  `live` = there is a previous M-tile (first body: zeros, effects off).
+    float ep8[2][4], eu[2], ew[2], em32[2], egu[2], egw[2], etmp0[2], etmp1[2];
     uint32_t ecu[2], ecw[2], eword[2];
-    // (`live` = there is a previous M-tile: in a run's first body the pieces run on zeros and only their two effects --
-    //  the group maximum and the store -- are switched off; a branch around every piece cost more than the pieces)
-    auto piece = [&](int P, int t, int k, int half, int64_t tile, bool live) {      // (P, t, k, half: constants once unrolled)
-        // every piece in two halves of at most three vector instructions: a 16-cycle MFMA leaves the vector issue 8 cycles
-        if (k == 0 || k == 2) {
-            const int r = k / 2;
-            const f32x4 v = acc[P][r][2 * t + half];
-            (half ? ey0[t] : ex0[t]) = rr_vmax3(v.x, v.y, rr_vmax(v.z, v.w));
-        } else if (k == 1 || k == 3) {
-            if (half == 0) {
-                const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(ex0[t]), __float_as_uint(ey0[t]), false, false);
-                ex0[t] = __uint_as_float(rs[0]);
-                ey0[t] = __uint_as_float(rs[1]);
-            } else {
-                const float v = rr_vmax(ex0[t], ey0[t]);
-                if (k == 1) eu[t] = v;
-                else ew[t] = v;
-            }
-        } else if (k == 4) {
-            if (half == 0) {
-                const float mh = rr_vmax(eu[t], ew[t]);
-                const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
-                ex0[t] = __uint_as_float(rm[0]);
-                ey0[t] = __uint_as_float(rm[1]);
-            } else {
-                em32[t] = rr_vmax(ex0[t], ey0[t]);
-                gm[t] = live ? rr_vmax(gm[t], em32[t]) : gm[t];
-            }
+    auto piece = [&](int P, int t, int k, int64_t tile, bool live) {      // (P, t, k: constants once unrolled)
+        if (k < 4) {                                   // lane-local maxima of the four 8-row M-tiles' rows in this k half
+            ep8[t][k] = rr_vmax3(acc[P][t][4 * k], acc[P][t][4 * k + 1], rr_vmax(acc[P][t][4 * k + 2], acc[P][t][4 * k + 3]));
+        } else if (k == 4 || k == 6) {                 // pair M-tiles (0, 1) / (2, 3): v_permlane32_swap(x, y) = {x.lo, y.lo}, {x.hi, y.hi}
+            const int g = k == 4 ? 0 : 2;
+            const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ep8[t][g]), __float_as_uint(ep8[t][g + 1]), false, false);
+            etmp0[t] = __uint_as_float(rs[0]);
+            etmp1[t] = __uint_as_float(rs[1]);
         } else if (k == 5) {
-            if (half == 0) {
-                const uint32_t b = __float_as_uint(em32[t]);
-                eword[t] = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);
-            }
-        } else if (k == 6) {
-            if (half == 0) egu[t] = (em32[t] - eu[t]) * inv_step;
-            else egw[t] = (em32[t] - ew[t]) * inv_step;
+            eu[t] = rr_vmax(etmp0[t], etmp1[t]);       // lanes < 32: M-tile 0, lanes >= 32: M-tile 1
         } else if (k == 7) {
-            if (half == 0) {
-                const uint32_t cu = rr_cvt_u32_sat(egu[t]);
-                ecu[t] = cu < 12u ? cu : 12u;
-            } else {
-                const uint32_t cw = rr_cvt_u32_sat(egw[t]);
-                ecw[t] = cw < 12u ? cw : 12u;
-            }
+            ew[t] = rr_vmax(etmp0[t], etmp1[t]);       // M-tiles 2 / 3
         } else if (k == 8) {
-            if (half == 0) ecu[t] += (egu[t] >= 16.f ? 1u : 0u) + (egu[t] >= 24.f ? 1u : 0u);
-            else ecu[t] += (egu[t] >= 40.f ? 1u : 0u);
+            const float mh = rr_vmax(eu[t], ew[t]);
+            const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
+            etmp0[t] = __uint_as_float(rm[0]);
+            etmp1[t] = __uint_as_float(rm[1]);
         } else if (k == 9) {
-            if (half == 0) ecw[t] += (egw[t] >= 16.f ? 1u : 0u) + (egw[t] >= 24.f ? 1u : 0u);
-            else ecw[t] += (egw[t] >= 40.f ? 1u : 0u);
+            em32[t] = rr_vmax(etmp0[t], etmp1[t]);     // the tile maximum, in both halves
+            gm[t] = live ? rr_vmax(gm[t], em32[t]) : gm[t];
         } else if (k == 10) {
-            if (half == 0) {
-                const uint32_t mine = (ecu[t] | (ecw[t] << 8)) << code_shift;
-                const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
-                ecu[t] = rc[0];
-                ecw[t] = rc[1];
-            } else eword[t] |= ecu[t] | ecw[t];
+            const uint32_t b = __float_as_uint(em32[t]);
+            eword[t] = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);
         } else if (k == 11) {
-            if (half == 1 && h == 0 && live)
-                reinterpret_cast<uint32_t*>(gm_out)[tile * RR_FLT_MAXQ + qoff + 32 * t + c] = eword[t];   // ONE store
+            egu[t] = (em32[t] - eu[t]) * inv_step;
+        } else if (k == 12) {
+            egw[t] = (em32[t] - ew[t]) * inv_step;
+        } else if (k == 13) {
+            const uint32_t cu = rr_cvt_u32_sat(egu[t]);
+            ecu[t] = cu < 12u ? cu : 12u;
+        } else if (k == 14) {
+            const uint32_t cw = rr_cvt_u32_sat(egw[t]);
+            ecw[t] = cw < 12u ? cw : 12u;
+        } else if (k == 15) {
+            ecu[t] += (egu[t] >= 16.f ? 1u : 0u) + (egu[t] >= 24.f ? 1u : 0u);
+        } else if (k == 16) {
+            ecu[t] += (egu[t] >= 40.f ? 1u : 0u);
+        } else if (k == 17) {
+            ecw[t] += (egw[t] >= 16.f ? 1u : 0u) + (egw[t] >= 24.f ? 1u : 0u);
+        } else if (k == 18) {
+            ecw[t] += (egw[t] >= 40.f ? 1u : 0u);
+        } else if (k == 19) {
+            const uint32_t mine = (ecu[t] | (ecw[t] << 8)) << code_shift;
+            const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+            ecu[t] = rc[0];
+            ecw[t] = rc[1];
+        } else if (k == 20) {
+            eword[t] |= ecu[t] | ecw[t];
+        } else if (k == 21) {
+            if (h == 0 && live) reinterpret_cast<uint32_t*>(gm_out)[tile * RR_FLT_MAXQ + qoff + 32 * t + c] = eword[t];   // ONE store
         }
     };
     auto finish_tile = [&](int64_t pm) {              // group bookkeeping of the M-tile whose epilogue has just finished
@@ -857,23 +849,27 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
         }
     };
     auto canon_set = [&](int P, int64_t tile) {       // rows past the end (and NaNs) of the matrix's last, short M-tile -> -inf
-        const int64_t rbase = tile * 32 + 4 * (lane >> 4);
+        const int64_t rbase = tile * 32 + 4 * h;
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc[P][r][f] = rr_x3_canon(acc[P][r][f], rbase + 16 * r, G.n_rows);
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[P][f][4 * g], acc[P][f][4 * g + 1], acc[P][f][4 * g + 2], acc[P][f][4 * g + 3]};
+                v = rr_x3_canon(v, rbase + 8 * g, G.n_rows);
+                acc[P][f][4 * g] = v.x; acc[P][f][4 * g + 1] = v.y; acc[P][f][4 * g + 2] = v.z; acc[P][f][4 * g + 3] = v.w;
+            }
     };
 
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[1][r][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 16; ++e) acc[1][f][e] = 0.f;
     dma_tile(m0, 0);
     dma_tile(m0 + 1, 1);
     dma_tile(m0 + 2, 2);
     uint64_t dbg_wait = 0, dbg_mfma = 0, dbg_epi = 0;
     const uint64_t dbg_t0 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
-    constexpr int AD = 4;                             // A operands requested this many steps (4 MFMAs each) ahead
+    constexpr int AD = 4;                             // A operands requested this many K-steps (2 MFMAs each) ahead
     bf16x8 a[AD + 1];
     auto body = [&](auto PC, int64_t mt) {
         constexpr int P = decltype(PC)::value;        // accumulator set of THIS M-tile; 1 - P: the previous one's
@@ -888,28 +884,26 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
         __builtin_amdgcn_s_barrier();
         const uint64_t ts1 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
         if (have_prev && (mt - 1) * 32 + 32 > G.n_rows) canon_set(1 - P, mt - 1);
-        const uint32_t te = a_even + (uint32_t)buf * (TILE_UNITS * 16), to = a_odd + (uint32_t)buf * (TILE_UNITS * 16);
+        const uint32_t toff = (uint32_t)buf * (TILE_UNITS * 16);
 #pragma unroll
-        for (int i = 0; i < AD; ++i) RR_FLTQ_READ_A(a[i], te, to, i);
+        for (int i = 0; i < AD; ++i) RR_FLTQ_READ_A(a[i], toff, i);
 #pragma unroll
-        for (int i = 0; i < 24; ++i) {                // step i = 2 ks + hf: row half hf of K-step ks
-            const int ks = i >> 1, hf = i & 1;
-            if (i + AD < 24) RR_FLTQ_READ_A(a[(i + AD) % (AD + 1)], te, to, i + AD);
-            // reads return in order: with the (up to AD) younger ones outstanding, step i's is in
-            if (i + AD < 24) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(AD) : "memory");
-            else if (23 - i == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-            else if (23 - i == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-            else if (23 - i == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        for (int ks = 0; ks < 24; ++ks) {             // 16-dim K-steps: one A operand, two MFMAs (the wave's two query fragments)
+            if (ks + AD < 24) RR_FLTQ_READ_A(a[(ks + AD) % (AD + 1)], toff, ks + AD);
+            // reads return in order: with the (up to AD) younger ones outstanding, this K-step's is in
+            if (ks + AD < 24) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(AD) : "memory");
+            else if (23 - ks == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            else if (23 - ks == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else if (23 - ks == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(a[i % (AD + 1)]));
+            asm volatile("" : "+v"(a[ks % (AD + 1)]));
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                if (ks == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[P][hf][f]) : "v"(a[i % (AD + 1)]), "a"(bq[ks][f]));
-                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[P][hf][f]) : "v"(a[i % (AD + 1)]), "a"(bq[ks][f]));
-                if (f & 1) {
-                    piece(1 - P, i / 12, i % 12, f >> 1, mt - 1, have_prev);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int f = 0; f < 2; ++f) {
+                if (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
+                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
+                __builtin_amdgcn_sched_barrier(0);      // the piece stands BEHIND its MFMA (in front of it, it would only delay it)
+                piece(1 - P, (2 * ks + f) / 24, (2 * ks + f) % 24, mt - 1, have_prev);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         const uint64_t ts2 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
@@ -926,16 +920,12 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
         body(std::integral_constant<int, 1>{}, mt + 1);
     }
     // tail: the last M-tile (set 1) has its epilogue to run
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0][0]), "+v"(acc[1][0][1]), "+v"(acc[1][0][2]), "+v"(acc[1][0][3]),
-                 "+v"(acc[1][1][0]), "+v"(acc[1][1][1]), "+v"(acc[1][1][2]), "+v"(acc[1][1][3]) :: "memory");
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
     if ((m1 - 1) * 32 + 32 > G.n_rows) canon_set(1, m1 - 1);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            piece(1, t, k, 0, m1 - 1, true);
-            piece(1, t, k, 1, m1 - 1, true);
-        }
+        for (int kk = 0; kk < 24; ++kk) piece(1, t, kk, m1 - 1, true);
     finish_tile(m1 - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) pieces
     if ((DBG & 128) && stamps && lane == 0) {
@@ -1336,8 +1326,8 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
     // two segments per M-tile and the pair's lock-step window would be twice as wide.
     static const bool no_dual = getenv("RR_NO_DUAL") != nullptr;
     const bool dual = SCAN_BF16 && !no_dual;
-    // RR_FLT_Q=1: the query-stationary kernel for the two-set launch (rows through LDS once per CU)
-    static const bool use_q = getenv("RR_FLT_Q") != nullptr;
+    // the two-set launch runs the query-stationary kernel (rows through LDS once per CU); RR_NO_FLTQ=1: rr_scan_flt16<.., DUAL>
+    static const bool use_q = getenv("RR_NO_FLTQ") == nullptr;
     const bool fltq = dual && use_q;
     const rr_scan_geom G = fltq ? rr_fltq_geom(ix) : rr_flt_geom<4, SCAN_BF16>(ix, dual);
     const float *sg0 = nullptr, *sg1 = nullptr;

@@ -48,12 +48,15 @@ def default_answer():
     return run_child({})
 
 
-@pytest.mark.parametrize("switch", ["RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR", "RR_NO_PREFILTER",
-                                    "RR_NO_SHADOW"])
+@pytest.mark.parametrize("switch", ["RR_NO_FLTQ", "RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR",
+                                    "RR_NO_PREFILTER", "RR_NO_SHADOW"])
 def test_switch_gives_the_default_answer(default_answer, switch):
     """rows AND scores bitwise: every filter path rescores its candidates with the single-query chain.  (RR_SCAN_EXACT is
     not in the list: it serves with split-operand arithmetic, equal to fp32 rounding -- near-ties may swap; its parity
     is checked against the oracle in test_gpu_dense.py.)"""
-    got = run_child({switch: "1"})
+    env = {switch: "1"}
+    if switch in ("RR_NO_COUPLE", "RR_DUAL_PREFILTER"):
+        env["RR_NO_FLTQ"] = "1"                       # these two act on the rr_scan_flt16 form of the two-set launch
+    got = run_child(env)
     for nq, (rows_h, sims_h) in default_answer.items():
         assert got[nq][0] == rows_h and got[nq][1] == sims_h, (switch, nq)
