@@ -1527,8 +1527,7 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
             *out_ms = rr_debug_time_flt<192, true>(ix, st, reps);
             break;
-        // 400 / 401 / 402 (16x16x32 kernel only; wrong results): stamped, cached, without the B-fragment reads / without the
-        // ring re-loads, waits and tile-word stores / without either = the bare MFMA chain + epilogue
+        // 400 (16x16x32 kernel only; wrong results): stamped, cached, without the B-fragment reads
         case 600: {       // rr_scan_fltq stamped (a 256-query search must have run: planes of both sets, scratch)
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
             const rr_scan_geom G = rr_fltq_geom(ix);
@@ -1564,14 +1563,9 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
             *out_ms = rr_debug_time_flt<192 | 2, true>(ix, st, reps);
             break;
-        case 401:
-            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
-            *out_ms = rr_debug_time_flt<192 | 4, true>(ix, st, reps);
-            break;
-        case 402:
-            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
-            *out_ms = rr_debug_time_flt<192 | 6, true>(ix, st, reps);
-            break;
+        // (401 / 402 -- without the ring re-loads / without both -- produced r02_flt16_stamps_ablations_10M.txt and are gone: a
+        //  variant that leaves asynchronously written registers unread lets the compiler hand them out again while the write
+        //  is still on its way; one such build faulted on the GPU.  The same goes for MFMA results nobody reads.)
         default: RR_REQUIRE(false, "unknown ablation %d", dbg);
     }
     RR_HIP_TRY(hipGetLastError());
