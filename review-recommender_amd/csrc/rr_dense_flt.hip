@@ -903,12 +903,17 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
                 else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
                 __builtin_amdgcn_sched_barrier(0);      // the piece stands BEHIND its MFMA (in front of it, it would only delay it)
                 piece(1 - P, (2 * ks + f) / 24, (2 * ks + f) % 24, mt - 1, have_prev);
+                // the epilogue has no piece for the last two MFMAs of a block: four of the wave's six LDS-DMA pieces of the
+                // M-tile three ahead go there (its buffer held M-tile mt - 1: read out, see the barrier), the other two
+                // behind two of the smallest pieces
+                if ((2 * ks + f) % 24 >= 22) dma_tile(mt + 3, (it + 3) & (NB - 1), 2 * ((2 * ks + f) / 24) + (2 * ks + f) % 24 - 22,
+                                                      2 * ((2 * ks + f) / 24) + (2 * ks + f) % 24 - 21);
+                if (2 * ks + f == 5) dma_tile(mt + 3, (it + 3) & (NB - 1), 4, 5);      // (behind two one-instruction pieces)
+                if (2 * ks + f == 7) dma_tile(mt + 3, (it + 3) & (NB - 1), 5, 6);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         const uint64_t ts2 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
-        // the wave's six pieces of the M-tile three ahead (the buffer held M-tile mt - 1: read out, see the barrier)
-        dma_tile(mt + 3, (it + 3) & (NB - 1));
         if (have_prev) finish_tile(mt - 1);
         if (DBG & 128) {
             const uint64_t ts3 = __builtin_amdgcn_s_memtime();
