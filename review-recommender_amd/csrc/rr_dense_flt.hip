@@ -788,44 +788,37 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     auto piece = [&](int P, int t, int k, int64_t tile, bool live) {      // (P, t, k: constants once unrolled)
         if (k < 4) {                                   // lane-local maxima of the four 8-row M-tiles' rows in this k half
             ep8[t][k] = rr_vmax3(acc[P][t][4 * k], acc[P][t][4 * k + 1], rr_vmax(acc[P][t][4 * k + 2], acc[P][t][4 * k + 3]));
-        } else if (k == 4 || k == 6) {                 // pair M-tiles (0, 1) / (2, 3): v_permlane32_swap(x, y) = {x.lo, y.lo}, {x.hi, y.hi}
+        } else if (k == 4 || k == 5) {                 // pair M-tiles (0, 1) / (2, 3): v_permlane32_swap(x, y) = {x.lo, y.lo}, {x.hi, y.hi}
             const int g = k == 4 ? 0 : 2;
             const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ep8[t][g]), __float_as_uint(ep8[t][g + 1]), false, false);
-            etmp0[t] = __uint_as_float(rs[0]);
-            etmp1[t] = __uint_as_float(rs[1]);
-        } else if (k == 5) {
-            eu[t] = rr_vmax(etmp0[t], etmp1[t]);       // lanes < 32: M-tile 0, lanes >= 32: M-tile 1
-        } else if (k == 7) {
-            ew[t] = rr_vmax(etmp0[t], etmp1[t]);       // M-tiles 2 / 3
-        } else if (k == 8) {
+            const float v = rr_vmax(__uint_as_float(rs[0]), __uint_as_float(rs[1]));
+            if (k == 4) eu[t] = v;                     // lanes < 32: M-tile 0, lanes >= 32: M-tile 1
+            else ew[t] = v;                            // M-tiles 2 / 3
+        } else if (k == 6) {
             const float mh = rr_vmax(eu[t], ew[t]);
             const auto rm = __builtin_amdgcn_permlane32_swap(__float_as_uint(mh), __float_as_uint(mh), false, false);
             etmp0[t] = __uint_as_float(rm[0]);
             etmp1[t] = __uint_as_float(rm[1]);
-        } else if (k == 9) {
+        } else if (k == 7) {
             em32[t] = rr_vmax(etmp0[t], etmp1[t]);     // the tile maximum, in both halves
             gm[t] = live ? rr_vmax(gm[t], em32[t]) : gm[t];
-        } else if (k == 10) {
+        } else if (k == 8) {
             const uint32_t b = __float_as_uint(em32[t]);
             eword[t] = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);
-        } else if (k == 11) {
+        } else if (k == 9) {
             egu[t] = (em32[t] - eu[t]) * inv_step;
-        } else if (k == 12) {
+        } else if (k == 10) {
             egw[t] = (em32[t] - ew[t]) * inv_step;
-        } else if (k == 13) {
+        } else if (k == 11) {
             const uint32_t cu = rr_cvt_u32_sat(egu[t]);
             ecu[t] = cu < 12u ? cu : 12u;
-        } else if (k == 14) {
+        } else if (k == 12) {
             const uint32_t cw = rr_cvt_u32_sat(egw[t]);
             ecw[t] = cw < 12u ? cw : 12u;
-        } else if (k == 15) {
-            ecu[t] += (egu[t] >= 16.f ? 1u : 0u) + (egu[t] >= 24.f ? 1u : 0u);
-        } else if (k == 16) {
-            ecu[t] += (egu[t] >= 40.f ? 1u : 0u);
-        } else if (k == 17) {
-            ecw[t] += (egw[t] >= 16.f ? 1u : 0u) + (egw[t] >= 24.f ? 1u : 0u);
-        } else if (k == 18) {
-            ecw[t] += (egw[t] >= 40.f ? 1u : 0u);
+        } else if (k >= 13 && k <= 15) {               // one threshold of the coarse codes per piece
+            ecu[t] += egu[t] >= (k == 13 ? 16.f : k == 14 ? 24.f : 40.f) ? 1u : 0u;
+        } else if (k >= 16 && k <= 18) {
+            ecw[t] += egw[t] >= (k == 16 ? 16.f : k == 17 ? 24.f : 40.f) ? 1u : 0u;
         } else if (k == 19) {
             const uint32_t mine = (ecu[t] | (ecw[t] << 8)) << code_shift;
             const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
