@@ -97,8 +97,10 @@ int rr_index_last_scan_ms(rr_index* ix, float* out_ms);
  * Drains the pairs recorded since the last call: total ms and launch count. */
 int rr_index_scan_stats(rr_index* ix, double* out_total_ms, int64_t* out_launches);
 /* Which scan kernel the last scan launch on this handle ran: out8[0] = 1 rr_scan_f32, 2 rr_scan_bf16,
- * 3 rr_scan_mfma_x3, 4 rr_scan_x3w, 5 rr_scan_flt, 6 rr_scan_mfma_f32, 7 rr_scan_mfma_bf16; [1] = its template
- * variant (query tiles / query slots); [2] = queries in that launch; [3] = bf16 MFMA terms per dimension
+ * 3 rr_scan_mfma_x3, 4 rr_scan_x3w, 5 the filter scans (rr_scan_flt over fp32 rows; over a bf16 stream rr_scan_flt16
+ * and, for two query sets in one launch, rr_scan_fltq), 6 rr_scan_mfma_f32, 7 rr_scan_mfma_bf16; [1] = its template
+ * variant (query tiles / query slots; filter scans: 8 = rr_scan_flt16 serving two query sets, 9 = rr_scan_fltq);
+ * [2] = queries in that launch; [3] = bf16 MFMA terms per dimension
  * (0: not a bf16 matrix-core kernel); [4] = bytes per matrix element the scan streamed (2 = bf16 rows or the bf16
  * filter plane, 4 = fp32 rows).  bench.py names the roofline kernel and its algorithmic bytes from this. */
 int rr_index_last_scan_info(rr_index* ix, int32_t* out8);
