@@ -704,19 +704,22 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
 // Per M-tile and wave: 96 MFMAs (16x16x32), 24 ds_read_b128, 6 LDS-DMA pieces, one raw s_barrier, the epilogue of its
 // 64 queries (two 32-query blocks, as in rr_scan_flt16) and two tile-word stores.  Runs: one per workgroup (G.n_waves =
 // number of runs), groups = 1/32 of a run.
-template <int DBG = 0>
-__global__ __launch_bounds__(256, 1) void rr_scan_fltq(
+// NW = waves per workgroup: 4 (one per SIMD, 64 queries each) or 8 (two per SIMD, 32 queries each)
+template <int DBG = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [256][48] units: set 0, then set 1
     float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq_a, int nq_b,
     int64_t gmax_set_stride, unsigned long long* __restrict__ stamps = nullptr) {      // stamps: DBG & 128, [run][wave][4]
     constexpr int NB = 4;                             // ring of M-tile images
+    constexpr int F = 8 / NW;                         // 32-query fragments per wave
+    constexpr int PW = 24 / NW;                       // LDS-DMA pieces per wave and M-tile
     constexpr int TILE_UNITS = 32 * RR_X3_UNITS;      // 16-byte units per image (24 KB)
     __shared__ u32x4 ring[NB * TILE_UNITS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int run = blockIdx.x;
     if (run >= G.n_waves) return;                     // (whole workgroup)
-    const int set = w >> 1;
-    const int qoff = 64 * (w & 1);                    // this wave's first query inside its set
+    const int set = w / (NW / 2);
+    const int qoff = 32 * F * (w % (NW / 2));         // this wave's first query inside its set
     const int nq = set ? nq_b : nq_a;
     float* const gm_out = gmax + set * gmax_set_stride;
     uint32_t* const sm_out = smax + (size_t)set * RR_FLT_MAXQ * RR_MAX_SCAN_WAVES;
@@ -727,19 +730,19 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
 
     // ---- B fragments (v_mfma_f32_32x32x16_bf16: 32 queries x 16 dims): query 32 f + (l & 31) of this wave, dims 16 ks +
     // 8 (l >> 5) .. + 7  ->  bq[ks][f], accumulation registers (2 x 24 x 4 = 192)
-    u32x4 bq[24][2];
+    u32x4 bq[24][F];
     {
-        const u32x4* src = plane + ((size_t)(64 * w + (lane & 31)) * RR_X3_UNITS + (lane >> 5));
+        const u32x4* src = plane + ((size_t)(32 * F * w + (lane & 31)) * RR_X3_UNITS + (lane >> 5));
 #pragma unroll
         for (int ks = 0; ks < 24; ++ks)
 #pragma unroll
-            for (int f = 0; f < 2; ++f)
+            for (int f = 0; f < F; ++f)
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[ks][f]) : "v"(src + (32 * f) * RR_X3_UNITS + 2 * ks) : "memory");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ks = 0; ks < 24; ++ks)
 #pragma unroll
-            for (int f = 0; f < 2; ++f) asm volatile("" : "+a"(bq[ks][f]));
+            for (int f = 0; f < F; ++f) asm volatile("" : "+a"(bq[ks][f]));
     }
 
     // ---- LDS-DMA: wave w brings rows 8 w .. 8 w + 7 of an M-tile, segment j = bytes 128 j .. 128 j + 127 of each row;
@@ -747,15 +750,16 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     // row r8 of row group w in slot p ^ r8 ^ (w >> 1): the A reads below (32 rows x one 16-byte piece per half wave) then
     // touch every bank group once per 16-lane access group
     const int d_r8 = lane >> 3, d_slot = lane & 7;
-    auto dma_tile = [&](int64_t mt, int buf, int j0 = 0, int j1 = 6) {      // pieces j0 .. j1 - 1 of the wave's six
+    const int rg = w * 4 / NW, jbase = (w % (NW / 4)) * PW;      // this wave's row group (8 rows) and first line segment
+    auto dma_tile = [&](int64_t mt, int buf, int j0 = 0, int j1 = 24) {      // pieces j0 .. j1 - 1 of the wave's PW (default: all)
         mt = mt < m1 ? mt : m1 - 1;                   // (past the end: redundant, never read)
         if (DBG & 64) mt = m0 + (mt & 1);             // timing only: cache hits
-        int64_t row = mt * 32 + 8 * w + d_r8;
+        int64_t row = mt * 32 + 8 * rg + d_r8;
         row = row < G.n_rows ? row : G.n_rows - 1;
-        const u32x4* src = mat + row * RR_X3_UNITS + (d_slot ^ d_r8 ^ (w >> 1));
-        u32x4* dst = ring + buf * TILE_UNITS + (w * 6) * 64;
+        const u32x4* src = mat + row * RR_X3_UNITS + (d_slot ^ d_r8 ^ (rg >> 1)) + 8 * jbase;
+        u32x4* dst = ring + buf * TILE_UNITS + (rg * 6 + jbase) * 64;
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < PW; ++j)
             if (j >= j0 && j < j1)
                 __builtin_amdgcn_global_load_lds(src + 8 * j, (__attribute__((address_space(3))) void*)(dst + j * 64), 16, 0, 0);
     };
@@ -774,8 +778,10 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     const uint32_t code_shift = 16u + 4u * (uint32_t)h;
     const float step = rr_flt_gap_step(eps_set, nq);
     const float inv_step = step > 0.f ? 0.9999f / step : 0.f;
-    float gm[2] = {-INFINITY, -INFINITY};
-    f32x16 acc[2][2];                                 // [set P = M-tile parity][fragment of 32 queries]
+    float gm[F];
+#pragma unroll
+    for (int t = 0; t < F; ++t) gm[t] = -INFINITY;
+    f32x16 acc[2][F];                                 // [set P = M-tile parity][fragment of 32 queries]
 
     // ---- the epilogue of one M-tile for this wave's 64 queries: block t = fragment t = queries 32 t .. 32 t + 31.
     // C layout (lane (query c = l & 31, h = l >> 5), register 4 g + i): row 8 g + 4 h + i.  Pieces of at most three
@@ -783,8 +789,8 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     // with one wave per SIMD only what stands right behind an MFMA in program order issues in its shadow), on the
     // accumulator set that M-tile does not write.  24 pieces per block: MFMA 2 ks + f of the next M-tile runs piece
     // (t = its index / 24, k = its index % 24).  `live` = there is a previous M-tile (first body: zeros, effects off).
-    float ep8[2][4], eu[2], ew[2], em32[2], egu[2], egw[2], etmp0[2], etmp1[2];
-    uint32_t ecu[2], ecw[2], eword[2];
+    float ep8[F][4], eu[F], ew[F], em32[F], egu[F], egw[F], etmp0[F], etmp1[F];
+    uint32_t ecu[F], ecw[F], eword[F];
     auto piece = [&](int P, int t, int k, int64_t tile, bool live) {      // (P, t, k: constants once unrolled)
         if (k < 4) {                                   // lane-local maxima of the four 8-row M-tiles' rows in this k half
             ep8[t][k] = rr_vmax3(acc[P][t][4 * k], acc[P][t][4 * k + 1], rr_vmax(acc[P][t][4 * k + 2], acc[P][t][4 * k + 3]));
@@ -835,7 +841,7 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
         if ((pm & 1) == 1 && ((in_run + 1) % cg == 0 || pm == m1 - 1)) {
             const int64_t group = (int64_t)run * G.gpw + in_run / cg;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < F; ++t) {
                 if (h == 0) sm_out[group * RR_FLT_MAXQ + qoff + 32 * t + c] = rr_f2key(gm[t]);
                 gm[t] = -INFINITY;
             }
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     auto canon_set = [&](int P, int64_t tile) {       // rows past the end (and NaNs) of the matrix's last, short M-tile -> -inf
         const int64_t rbase = tile * 32 + 4 * h;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < F; ++f)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v = {acc[P][f][4 * g], acc[P][f][4 * g + 1], acc[P][f][4 * g + 2], acc[P][f][4 * g + 3]};
@@ -854,7 +860,7 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     };
 
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < F; ++f)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[1][f][e] = 0.f;
     dma_tile(m0, 0);
@@ -872,8 +878,9 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
         // this wave's six pieces of M-tile mt have landed once at most the two younger M-tiles' pieces (12) and the four
         // word stores issued with them are outstanding; then all four waves' pieces have, behind the barrier -- which also
         // says that every wave is done reading M-tile mt - 1
-        if (it < 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // (per M-tile and wave: PW pieces and F word stores)
+        if (it < 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PW + F)) : "memory");
         __builtin_amdgcn_s_barrier();
         const uint64_t ts1 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
         if (have_prev && (mt - 1) * 32 + 32 > G.n_rows) canon_set(1 - P, mt - 1);
@@ -891,18 +898,23 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(a[ks % (AD + 1)]));
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
+            for (int f = 0; f < F; ++f) {
+                constexpr int PB = 24;                  // pieces (= MFMAs) per 32-query block
+                const int idx = F * ks + f;             // MFMA of this M-tile: 0 .. 24 F - 1
                 if (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
                 else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
                 __builtin_amdgcn_sched_barrier(0);      // the piece stands BEHIND its MFMA (in front of it, it would only delay it)
-                piece(1 - P, (2 * ks + f) / 24, (2 * ks + f) % 24, mt - 1, have_prev);
-                // the epilogue has no piece for the last two MFMAs of a block: four of the wave's six LDS-DMA pieces of the
-                // M-tile three ahead go there (its buffer held M-tile mt - 1: read out, see the barrier), the other two
-                // behind two of the smallest pieces
-                if ((2 * ks + f) % 24 >= 22) dma_tile(mt + 3, (it + 3) & (NB - 1), 2 * ((2 * ks + f) / 24) + (2 * ks + f) % 24 - 22,
-                                                      2 * ((2 * ks + f) / 24) + (2 * ks + f) % 24 - 21);
-                if (2 * ks + f == 5) dma_tile(mt + 3, (it + 3) & (NB - 1), 4, 5);      // (behind two one-instruction pieces)
-                if (2 * ks + f == 7) dma_tile(mt + 3, (it + 3) & (NB - 1), 5, 6);
+                piece(1 - P, idx / PB, idx % PB, mt - 1, have_prev);
+                // the epilogue has no piece for the last two MFMAs of a block: the wave's LDS-DMA pieces of the M-tile three ahead
+                // go there (its buffer held M-tile mt - 1: read out, see the barrier), the rest behind the smallest pieces
+                if (NW == 4) {
+                    if (idx % PB >= 22) dma_tile(mt + 3, (it + 3) & (NB - 1), 2 * (idx / PB) + idx % PB - 22, 2 * (idx / PB) + idx % PB - 21);
+                    if (idx == 5) dma_tile(mt + 3, (it + 3) & (NB - 1), 4, 5);
+                    if (idx == 7) dma_tile(mt + 3, (it + 3) & (NB - 1), 5, 6);
+                } else {
+                    if (idx >= 22) dma_tile(mt + 3, (it + 3) & (NB - 1), idx - 22, idx - 21);
+                    if (idx == 5) dma_tile(mt + 3, (it + 3) & (NB - 1), 2, 3);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -918,23 +930,24 @@ __global__ __launch_bounds__(256, 1) void rr_scan_fltq(
         body(std::integral_constant<int, 1>{}, mt + 1);
     }
     // tail: the last M-tile (set 1) has its epilogue to run
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
+    if constexpr (F == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
+    else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0]) :: "memory");
     if ((m1 - 1) * 32 + 32 > G.n_rows) canon_set(1, m1 - 1);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < F; ++t)
 #pragma unroll
         for (int kk = 0; kk < 24; ++kk) piece(1, t, kk, m1 - 1, true);
     finish_tile(m1 - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) pieces
     if ((DBG & 128) && stamps && lane == 0) {
-        unsigned long long* o = stamps + ((size_t)run * 4 + w) * 4;
+        unsigned long long* o = stamps + ((size_t)run * NW + w) * 4;
         o[0] = dbg_wait; o[1] = dbg_mfma; o[2] = dbg_epi; o[3] = __builtin_amdgcn_s_memtime() - dbg_t0;
     }
     if (h == 0) {
         const int cg = (int)G.tiles_per_group;
         for (int k = (int)((t1 - t0 + cg - 1) / cg); k < G.gpw; ++k)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) sm_out[((int64_t)run * G.gpw + k) * RR_FLT_MAXQ + qoff + 32 * t + c] = 0u;
+            for (int t = 0; t < F; ++t) sm_out[((int64_t)run * G.gpw + k) * RR_FLT_MAXQ + qoff + 32 * t + c] = 0u;
     }
 }
 
@@ -1342,6 +1355,12 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
         const rr_x3_scratch X = rr_x3_scratch_of(ix);
         const int slot = rr_scan_events_begin(ix, st);
         rr_scan_note(ix, 5, 9, nq_a + nq_b, 1, 2);
+        static const bool w8 = getenv("RR_FLTQ_W8") != nullptr;
+        if (w8)
+            hipLaunchKernelGGL((rr_scan_fltq<0, 8>), dim3(G.n_waves), dim3(512), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+                               reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
+                               rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
+        else
         hipLaunchKernelGGL((rr_scan_fltq<0>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
                            reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
                            rr_flt_mmax_set_stride(G));

@@ -48,7 +48,7 @@ def default_answer():
     return run_child({})
 
 
-@pytest.mark.parametrize("switch", ["RR_NO_FLTQ", "RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR",
+@pytest.mark.parametrize("switch", ["RR_FLTQ_W8", "RR_NO_FLTQ", "RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR",
                                     "RR_NO_PREFILTER", "RR_NO_SHADOW"])
 def test_switch_gives_the_default_answer(default_answer, switch):
     """rows AND scores bitwise: every filter path rescores its candidates with the single-query chain.  (RR_SCAN_EXACT is
