@@ -1037,13 +1037,21 @@ template <bool A_BF16>
 __global__ __launch_bounds__(256) void rr_rescore_chain(
     const void* __restrict__ mat, int64_t n_rows, const float* __restrict__ queries,   // [nq][384] fp32, padded
     const uint32_t* __restrict__ mtiles, const int32_t* __restrict__ count, const int32_t* __restrict__ fb,
-    float* __restrict__ sc) {
+    float* __restrict__ sc,
+    // fp32 rows with a bf16 filter plane (null otherwise): a row is first scored on its plane row -- half the bytes --
+    // as sum a~_k q_k, which is within eps of its exact score (|sum (a~ - a) q| <= ||a - a~|| ||q||, plus the summation
+    // roundings the bound's 2^-14 term covers); the exact chain over the fp32 row runs only where that can reach the
+    // row cut tau (= key of tau~ - 1.02 eps): one row in eight of an opened M-tile, typically.  The others get -inf:
+    // they are below the cut whatever their exact score is.
+    const u32x4* __restrict__ plane_rows, const uint32_t* __restrict__ tau, const float* __restrict__ eps) {
     const int q = blockIdx.y;
     if (fb[q]) return;
     const int n = count[q];
     const int lane = threadIdx.x & 63;
     const int sub = lane & 15, grp = lane >> 4;
     const f32x4* qv = reinterpret_cast<const f32x4*>(queries + (int64_t)q * 384);
+    float pre_thr = (!A_BF16 && plane_rows) ? rr_key2f(tau[q]) - 1.01f * eps[q] : -INFINITY;
+    if (!(pre_thr == pre_thr)) pre_thr = -INFINITY;           // (a key that is not a score, a NaN bound: every row takes the exact chain)
     f32x4 qreg[6];
     if (A_BF16) {
 #pragma unroll
@@ -1079,15 +1087,35 @@ __global__ __launch_bounds__(256) void rr_rescore_chain(
                     acc = __builtin_fmaf(__uint_as_float(x.w & 0xFFFF0000u), q1.w, acc);
                 }
             } else {
-                const f32x4* p = static_cast<const f32x4*>(mat) + row * 96 + sub;
+                bool exact = true;
+                if (plane_rows) {
+                    // the plane row in the fp32 chain's own lane order: lane `sub` holds dims 4 (16 i + sub) .. + 3 of the
+                    // query (qreg[i]) and reads those four bf16 values (8 bytes) of the plane row
+                    const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(plane_rows + row * 48) + sub;
+                    float est = 0.f;
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const f32x4 x = p[16 * i];
-                    acc = __builtin_fmaf(x.x, qreg[i].x, acc);
-                    acc = __builtin_fmaf(x.y, qreg[i].y, acc);
-                    acc = __builtin_fmaf(x.z, qreg[i].z, acc);
-                    acc = __builtin_fmaf(x.w, qreg[i].w, acc);
+                    for (int i = 0; i < 6; ++i) {
+                        const unsigned long long x = pp[16 * i];
+                        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+                        est = __builtin_fmaf(__uint_as_float(lo << 16), qreg[i].x, est);
+                        est = __builtin_fmaf(__uint_as_float(lo & 0xFFFF0000u), qreg[i].y, est);
+                        est = __builtin_fmaf(__uint_as_float(hi << 16), qreg[i].z, est);
+                        est = __builtin_fmaf(__uint_as_float(hi & 0xFFFF0000u), qreg[i].w, est);
+                    }
+                    est = rr_row16_sum(est);
+                    exact = est >= pre_thr || !(est == est);          // (the 16 lanes of a row agree; NaN: let the exact chain decide)
                 }
+                if (exact) {
+                    const f32x4* p = static_cast<const f32x4*>(mat) + row * 96 + sub;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const f32x4 x = p[16 * i];
+                        acc = __builtin_fmaf(x.x, qreg[i].x, acc);
+                        acc = __builtin_fmaf(x.y, qreg[i].y, acc);
+                        acc = __builtin_fmaf(x.z, qreg[i].z, acc);
+                        acc = __builtin_fmaf(x.w, qreg[i].w, acc);
+                    }
+                } else acc = -INFINITY;
             }
             acc = rr_row16_sum(acc);
             mine = (sub == it) ? acc : mine;               // lane (sub, grp) keeps row 4 sub + grp (sub < 2)
@@ -1267,8 +1295,13 @@ static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, 
     const rr_x3_scratch X = rr_x3_scratch_of(ix);
     const int nq = nq_a + nq_b;
     rr_launch_select_mtiles(ix, G, nq_a, pool, st, X.eps, sigma, nq_b, rr_flt_mmax_set_stride(G), rr_flt_smax_set_stride(), floor);
+    // (the plane pre-scoring of the rescored rows: fp32 storage with a valid plane, and not in floor mode, where rows
+    //  below the shard's own cut may be taken to fill its list up and need their exact scores)
+    static const bool no_pre = getenv("RR_NO_RESCORE_PLANE") != nullptr;
+    const u32x4* plane_rows = (!ROWS_BF16 && ix->shadow_valid && ix->d_shadow && !floor && !no_pre)
+                                  ? reinterpret_cast<const u32x4*>(ix->d_shadow) : nullptr;
     hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
-                       X.mtiles, X.count, X.fb, X.sc);
+                       X.mtiles, X.count, X.fb, X.sc, plane_rows, X.tau, X.eps);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st, floor != nullptr);
     RR_HIP_TRY(hipGetLastError());
     // Flagged queries: the stored-score pass of the split-operand scan, 64 queries at a time; every

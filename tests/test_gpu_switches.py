@@ -49,7 +49,7 @@ def default_answer():
 
 
 @pytest.mark.parametrize("switch", ["RR_FLTQ_W8", "RR_NO_FLTQ", "RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR",
-                                    "RR_NO_PREFILTER", "RR_NO_SHADOW"])
+                                    "RR_NO_PREFILTER", "RR_NO_SHADOW", "RR_NO_RESCORE_PLANE"])
 def test_switch_gives_the_default_answer(default_answer, switch):
     """rows AND scores bitwise: every filter path rescores its candidates with the single-query chain.  (RR_SCAN_EXACT is
     not in the list: it serves with split-operand arithmetic, equal to fp32 rounding -- near-ties may swap; its parity
