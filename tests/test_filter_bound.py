@@ -51,3 +51,51 @@ def test_bound_is_not_vacuous_for_unit_vectors():
     q = V[17].copy()
     _, _, eps = _eps(V, q)
     assert 1e-3 < eps < 8e-3          # ~2 x 2^-8 / sqrt(3): a few thousandths of the score range
+
+
+def _fp32_chain(rows, q):
+    """The per-row arithmetic of rr_rescore_chain on fp32 operands: lane j of 16 takes 16-byte units j, j + 16, ... and
+    runs one fmaf chain over its 24 elements; the 16 partial sums are added pairwise (xor 8, 4, 2, 1).  float64 products
+    rounded once to float32 stand in for fmaf (exact here: a float32 product has 48 significant bits, the sum of it
+    and a float32 accumulator rounds once from float64 except in double-rounding ties that do not move the bound)."""
+    n = rows.shape[0]
+    lanes = np.zeros((n, 16), dtype=np.float32)
+    r4 = rows.reshape(n, 6, 16, 4)
+    q4 = q.reshape(6, 16, 4)
+    for i in range(6):
+        for e in range(4):
+            lanes = (lanes.astype(np.float64) + r4[:, i, :, e].astype(np.float64) * q4[i, :, e].astype(np.float64)).astype(np.float32)
+    for step in (8, 4, 2, 1):
+        lanes = lanes + lanes[:, np.arange(16) ^ step]
+    return lanes[:, 0]
+
+
+@pytest.mark.parametrize("kind", ["unit", "scaled"])
+def test_plane_prescoring_of_rescored_rows_never_drops_a_pool_row(kind):
+    """rr_rescore_chain scores a candidate row on its bf16 plane row first (sum a~_k q_k with the fp32 query) and runs
+    the exact chain only if that reaches tau - 1.01 eps, tau = tau~ - 1.02 eps: a row of the exact top-pool (exact score
+    >= tau~ - eps) always does, and at least `pool` rows do."""
+    rng = np.random.default_rng(11)
+    V = rng.standard_normal((20000, 384)).astype(np.float32)
+    q = rng.standard_normal(384).astype(np.float32)
+    if kind == "unit":
+        V /= np.linalg.norm(V, axis=1, keepdims=True)
+        q /= np.linalg.norm(q)
+    else:
+        V *= rng.uniform(0.01, 30.0, (len(V), 1)).astype(np.float32)
+        q *= np.float32(7.5)
+    Vr, qr, eps = _eps(V, q)
+    pool = 150
+    s_scan = Vr @ qr                                          # what the filter scan estimates
+    tau_est = np.sort(s_scan)[-pool]
+    exact = _fp32_chain(V, q)
+    est = _fp32_chain(Vr.astype(np.float32), q)               # the plane row against the fp32 query
+    assert np.abs(est.astype(np.float64) - exact.astype(np.float64)).max() <= eps
+    pre_thr = (tau_est - 1.02 * eps) - 1.01 * eps
+    takes_chain = est >= pre_thr
+    needed = exact >= tau_est - eps
+    assert not (needed & ~takes_chain).any()
+    assert takes_chain.sum() >= pool
+    top = np.argsort(-exact.astype(np.float64), kind="stable")[:pool]
+    assert takes_chain[top].all()
+    assert takes_chain.mean() < 0.5                           # and it does skip rows: not a vacuous test
