@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import pathlib
 import pickle
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import pandas as pd

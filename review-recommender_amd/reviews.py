@@ -11,7 +11,7 @@ candidates (csrc/rr_reviews.hip).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Sequence
 
 import numpy as np
 import pandas as pd

@@ -11,7 +11,7 @@ local `vocab.txt`; nothing is fetched.
 from __future__ import annotations
 
 import unicodedata
-from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
