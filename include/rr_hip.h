@@ -278,10 +278,6 @@ int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_ty
 /* HIP-event time of the last forward pass on this handle (ms). */
 int rr_ce_last_forward_ms(rr_ce* ce, float* out_ms);
 
-/* Development aid (tools/x3w_ablate.py): times ablated variants of the 64-query fp32 batched scan
- * (bit 0: no operand split, bit 1: no B-fragment reads, bit 2: no MFMA, bit 3: no lane swap).
- * Leaves garbage in the scan scratch; never part of a search. */
-int rr_debug_scan_x3w(rr_index* ix, int32_t variant, int32_t reps, float* out_ms);
 /* Two-phase K1 for ROW SHARDS (sharded.py: one process per GPU, this shard's rows in `ix`).  A shard's
  * own top-`top_k` threshold sits far below the corpus-wide one (rank 150 of 1.25M rows ~ rank 1 200 of 10M), so a shard
  * that selects on its own rescoring ~8x the candidates the merged answer needs.  Instead:
@@ -300,10 +296,6 @@ int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n_queries, i
                       float* d_bound, int32_t* applied, void* stream);
 int rr_dense_select_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t top_k,
                         const float* d_floor, int64_t* d_out_rows, float* d_out_scores, void* stream);
-
-/* The same for the 128-query fp32 filter scan (bit 0: no epilogue, bit 1: no B-fragment reads, bit 2: no
- * MFMA, bit 3: no lane swaps / conversions). */
-int rr_debug_scan_flt(rr_index* ix, int32_t variant, int32_t reps, float* out_ms);
 
 /* Stream helpers for callers that chain *_dev calls. */
 int rr_index_stream(rr_index* ix, void** out_stream);

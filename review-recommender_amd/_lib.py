@@ -3,9 +3,10 @@ library is missing or a call fails, this raises."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 
-from .build import LIB_PATH
+from .build import DEBUG_LIB_PATH, LIB_PATH
 
 c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 P = C.POINTER
@@ -49,10 +50,8 @@ PROTOTYPES = {
     "rr_index_select_trace": (C.c_int, [c_vp, P(c_i32)]),
     "rr_index_set_shadow": (C.c_int, [c_vp, c_i32]),
     "rr_index_set_scan_mode": (C.c_int, [c_vp, c_i32]),
-    "rr_debug_scan_x3w": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
     "rr_dense_scan_dev": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, P(c_i32), c_vp]),
     "rr_dense_select_dev": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
-    "rr_debug_scan_flt": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
     "rr_bm25_create": (C.c_int, [c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_vp, c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, P(c_vp)]),
     "rr_bm25_create_dev": (C.c_int, [c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -76,6 +75,13 @@ PROTOTYPES = {
     "rr_index_synchronize": (C.c_int, [c_vp]),
 }
 
+# csrc/rr_debug.h: only in librr_hip_dbg.so (RR_DEBUG_HARNESS=1 in the environment; tools/ only, never the product)
+DEBUG_PROTOTYPES = {
+    "rr_debug_scan_x3w": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
+    "rr_debug_scan_flt": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
+    "rr_debug_fltq_compare": (C.c_int, [c_vp, P(c_i64)]),
+}
+
 _lib = None
 _lock = threading.Lock()
 
@@ -90,16 +96,19 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        if not LIB_PATH.exists():
+        debug = os.environ.get("RR_DEBUG_HARNESS") == "1"
+        path = DEBUG_LIB_PATH if debug else LIB_PATH
+        if not path.exists():
             raise HipLibraryError(
-                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                f"{path} is missing: build it with `python __graft_entry__.py` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
         # torch ships its own HIP runtime (libamdhip64, SONAME .7).  Importing it first makes
         # the dynamic linker bind librr_hip.so to that same runtime; loaded the other way
         # round the process would hold two runtimes and the second one sees no device.
         import torch  # noqa: F401
-        lib = C.CDLL(str(LIB_PATH))
-        for name, (res, args) in PROTOTYPES.items():
+        lib = C.CDLL(str(path))
+        protos = dict(PROTOTYPES, **DEBUG_PROTOTYPES) if debug else PROTOTYPES
+        for name, (res, args) in protos.items():
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args

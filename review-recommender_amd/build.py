@@ -20,6 +20,11 @@ CSRC = PKG_DIR / "csrc"
 OBJ_DIR = PKG_DIR / "build"
 LIB_PATH = PKG_DIR / "librr_hip.so"
 BUILD_ID = PKG_DIR / "librr_hip.so.buildid"
+# the ablation harness (csrc/rr_debug.h) lives in a library of its own, built on demand for tools/ only
+DEBUG_OBJ_DIR = PKG_DIR / "build_dbg"
+DEBUG_LIB_PATH = PKG_DIR / "librr_hip_dbg.so"
+DEBUG_BUILD_ID = PKG_DIR / "librr_hip_dbg.so.buildid"
+DEBUG_FLAGS = ["-DRR_DEBUG_HARNESS"]
 SOURCES = ["rr_api.hip", "rr_dense.hip", "rr_dense_bf16.hip", "rr_dense_x3.hip", "rr_dense_x3w.hip",
            "rr_dense_flt.hip", "rr_bm25.hip", "rr_fuse.hip", "rr_reviews.hip", "rr_ce.hip"]
 # -ffp-contract=off: the BM25 and fusion kernels reproduce numpy's one-rounding-per-
@@ -35,7 +40,15 @@ def hipcc_path() -> str:
 
 
 def _headers():
-    return sorted(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "rr_hip.h"]
+    return sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + [PKG_DIR.parent / "include" / "rr_hip.h"]
+
+
+def check_generated() -> None:
+    """csrc/rr_fltq_loop.inc is generated (gen_fltq_loop.py) and committed: a stale copy must not build."""
+    gen = subprocess.run([os.sys.executable, str(CSRC / "gen_fltq_loop.py")], capture_output=True, text=True, check=True)
+    inc = CSRC / "rr_fltq_loop.inc"
+    if not inc.exists() or inc.read_text() != gen.stdout:
+        inc.write_text(gen.stdout)
 
 
 def _digest(paths, extra: str = "") -> str:
@@ -46,27 +59,33 @@ def _digest(paths, extra: str = "") -> str:
     return h.hexdigest()
 
 
-def _source_digest(src: str) -> str:
-    return _digest([CSRC / src] + _headers(), " ".join(FLAGS))
+def _flags(debug: bool):
+    return FLAGS + (DEBUG_FLAGS if debug else [])
 
 
-def library_digest() -> str:
-    return _digest([CSRC / s for s in SOURCES] + _headers(), " ".join(FLAGS))
+def _source_digest(src: str, debug: bool = False) -> str:
+    return _digest([CSRC / src] + _headers(), " ".join(_flags(debug)))
 
 
-def needs_build() -> bool:
-    if not LIB_PATH.exists() or not BUILD_ID.exists():
+def library_digest(debug: bool = False) -> str:
+    return _digest([CSRC / s for s in SOURCES] + _headers(), " ".join(_flags(debug)))
+
+
+def needs_build(debug: bool = False) -> bool:
+    lib, bid = (DEBUG_LIB_PATH, DEBUG_BUILD_ID) if debug else (LIB_PATH, BUILD_ID)
+    if not lib.exists() or not bid.exists():
         return True
-    return BUILD_ID.read_text().strip() != library_digest()
+    return bid.read_text().strip() != library_digest(debug)
 
 
-def _compile_one(src: str, verbose: bool) -> pathlib.Path:
-    obj = OBJ_DIR / (src + ".o")
-    tag = OBJ_DIR / (src + ".sha256")
-    want = _source_digest(src)
+def _compile_one(src: str, verbose: bool, debug: bool = False) -> pathlib.Path:
+    obj_dir = DEBUG_OBJ_DIR if debug else OBJ_DIR
+    obj = obj_dir / (src + ".o")
+    tag = obj_dir / (src + ".sha256")
+    want = _source_digest(src, debug)
     if obj.exists() and tag.exists() and tag.read_text().strip() == want:
         return obj
-    cmd = [hipcc_path(), *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+    cmd = [hipcc_path(), *_flags(debug), "-c", str(CSRC / src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
@@ -76,25 +95,30 @@ def _compile_one(src: str, verbose: bool) -> pathlib.Path:
     return obj
 
 
-def build_library(force: bool = False, verbose: bool = False, jobs: int = 0) -> pathlib.Path:
-    if not force and not needs_build():
-        return LIB_PATH
-    OBJ_DIR.mkdir(exist_ok=True)
+def build_library(force: bool = False, verbose: bool = False, jobs: int = 0, debug: bool = False) -> pathlib.Path:
+    """debug=True: librr_hip_dbg.so = the same sources + the ablation harness (-DRR_DEBUG_HARNESS), for tools/ only."""
+    lib_path, build_id, obj_dir = ((DEBUG_LIB_PATH, DEBUG_BUILD_ID, DEBUG_OBJ_DIR) if debug
+                                   else (LIB_PATH, BUILD_ID, OBJ_DIR))
+    check_generated()
+    if not force and not needs_build(debug):
+        return lib_path
+    obj_dir.mkdir(exist_ok=True)
     if force:
-        for f in OBJ_DIR.glob("*.sha256"):
+        for f in obj_dir.glob("*.sha256"):
             f.unlink()
     jobs = jobs or min(len(SOURCES), max(1, (os.cpu_count() or 2) - 1), 8)
     with cf.ThreadPoolExecutor(jobs) as ex:
-        objs = list(ex.map(lambda s: _compile_one(s, verbose), SOURCES))
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB_PATH)]
+        objs = list(ex.map(lambda s: _compile_one(s, verbose, debug), SOURCES))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(lib_path)]
     if verbose:
         print(" ".join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + proc.stdout + proc.stderr)
-    BUILD_ID.write_text(library_digest())
-    return LIB_PATH
+    build_id.write_text(library_digest(debug))
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    print(build_library(force="--force" in sys.argv, verbose=True, debug="--debug" in sys.argv))

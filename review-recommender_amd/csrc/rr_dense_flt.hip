@@ -705,7 +705,11 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
 // 64 queries (two 32-query blocks, as in rr_scan_flt16) and two tile-word stores.  Runs: one per workgroup (G.n_waves =
 // number of runs), groups = 1/32 of a run.
 // NW = waves per workgroup: 4 (one per SIMD, 64 queries each) or 8 (two per SIMD, 32 queries each)
-template <int DBG = 0, int NW = 4>
+// ASM: the steady-state M-tiles run through the hand-scheduled loop of rr_fltq_loop.inc (gen_fltq_loop.py): the same
+// MFMAs in the same order and the epilogue arithmetic of `piece()` bit for bit, so tile words and group maxima are those
+// of the C++ bodies -- which stay for the first five M-tiles of a run, the last few and the matrix's short last M-tile
+// (RR_FLTQ_NOASM=1 runs them everywhere: A/B and the ablation harness).
+template <int DBG = 0, int NW = 4, bool ASM = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [256][48] units: set 0, then set 1
     float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq_a, int nq_b,
@@ -870,6 +874,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
     const uint64_t dbg_t0 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
     constexpr int AD = 4;                             // A operands requested this many K-steps (2 MFMAs each) ahead
     bf16x8 a[AD + 1];
+    f32x4 acc16[2][F][2];                             // (DBG & 256 only)
+    if (DBG & 256) {
+#pragma unroll
+        for (int i = 0; i < 4 * F; ++i) acc16[i / (2 * F)][(i / 2) % F][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     auto body = [&](auto PC, int64_t mt) {
         constexpr int P = decltype(PC)::value;        // accumulator set of THIS M-tile; 1 - P: the previous one's
         const int it = (int)(mt - m0), buf = it & (NB - 1);
@@ -879,35 +888,50 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
         // word stores issued with them are outstanding; then all four waves' pieces have, behind the barrier -- which also
         // says that every wave is done reading M-tile mt - 1
         // (per M-tile and wave: PW pieces and F word stores)
-        if (it < 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PW + F)) : "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(DBG & 4)) {
+            if (it < 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PW + F)) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         const uint64_t ts1 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
         if (have_prev && (mt - 1) * 32 + 32 > G.n_rows) canon_set(1 - P, mt - 1);
         const uint32_t toff = (uint32_t)buf * (TILE_UNITS * 16);
+        if ((DBG & 8) && it == 0) {                   // (ablation: no A reads in the loop -- five once, then stale registers)
 #pragma unroll
-        for (int i = 0; i < AD; ++i) RR_FLTQ_READ_A(a[i], toff, i);
+            for (int i = 0; i <= AD; ++i) RR_FLTQ_READ_A(a[i], toff, i);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < AD; ++i)
+            if (!(DBG & 8)) RR_FLTQ_READ_A(a[i], toff, i);
 #pragma unroll
         for (int ks = 0; ks < 24; ++ks) {             // 16-dim K-steps: one A operand, two MFMAs (the wave's two query fragments)
-            if (ks + AD < 24) RR_FLTQ_READ_A(a[(ks + AD) % (AD + 1)], toff, ks + AD);
-            // reads return in order: with the (up to AD) younger ones outstanding, this K-step's is in
-            if (ks + AD < 24) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(AD) : "memory");
-            else if (23 - ks == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-            else if (23 - ks == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-            else if (23 - ks == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!(DBG & 8)) {
+                if (ks + AD < 24) RR_FLTQ_READ_A(a[(ks + AD) % (AD + 1)], toff, ks + AD);
+                // reads return in order: with the (up to AD) younger ones outstanding, this K-step's is in
+                if (ks + AD < 24) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(AD) : "memory");
+                else if (23 - ks == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                else if (23 - ks == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                else if (23 - ks == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             asm volatile("" : "+v"(a[ks % (AD + 1)]));
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 constexpr int PB = 24;                  // pieces (= MFMAs) per 32-query block
                 const int idx = F * ks + f;             // MFMA of this M-tile: 0 .. 24 F - 1
-                if (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
+                if (DBG & 256) {                        // (ablation, wrong results: the same MACs as two 16x16x32 MFMAs, 16 cycles each)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[P][f][0]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[P][f][1]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
+                }
+                else if (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
                 else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
                 __builtin_amdgcn_sched_barrier(0);      // the piece stands BEHIND its MFMA (in front of it, it would only delay it)
-                piece(1 - P, idx / PB, idx % PB, mt - 1, have_prev);
+                if (!(DBG & 2) && (!(DBG & 512) || idx % PB < 8)) piece(1 - P, idx / PB, idx % PB, mt - 1, have_prev);
                 // the epilogue has no piece for the last two MFMAs of a block: the wave's LDS-DMA pieces of the M-tile three ahead
                 // go there (its buffer held M-tile mt - 1: read out, see the barrier), the rest behind the smallest pieces
-                if (NW == 4) {
+                if (DBG & 1) {                       // (ablation: no LDS-DMA in the loop; the A operands are stale LDS bytes)
+                } else if (NW == 4) {
                     if (idx % PB >= 22) dma_tile(mt + 3, (it + 3) & (NB - 1), 2 * (idx / PB) + idx % PB - 22, 2 * (idx / PB) + idx % PB - 21);
                     if (idx == 5) dma_tile(mt + 3, (it + 3) & (NB - 1), 4, 5);
                     if (idx == 7) dma_tile(mt + 3, (it + 3) & (NB - 1), 5, 6);
@@ -919,15 +943,79 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
             }
         }
         const uint64_t ts2 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
-        if (have_prev) finish_tile(mt - 1);
+        if (have_prev && !(DBG & 2)) finish_tile(mt - 1);
         if (DBG & 128) {
             const uint64_t ts3 = __builtin_amdgcn_s_memtime();
             dbg_wait += ts1 - ts0; dbg_mfma += ts2 - ts1; dbg_epi += ts3 - ts2;
         }
     };
+    if constexpr (ASM && NW == 4 && DBG == 0) {
+        // ---- wave-uniform operands of the hand-scheduled loop (SGPRs: readfirstlane, the compiler sees tid >> 6 per lane)
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        const uint32_t lds_w = __builtin_amdgcn_readfirstlane(ring_lds) + (uint32_t)wu * (PW * 1024);
+        const uint32_t dma_voff = (uint32_t)d_r8 * 768u + 16u * (uint32_t)(d_slot ^ d_r8 ^ (wu >> 1));
+        const uint32_t st_voff = h == 0 ? (uint32_t)(qoff + c) * 4u : 0xFFFFF000u;      // (upper half: out of range, dropped)
+        const uint32_t inv_step_s = __builtin_amdgcn_readfirstlane(__float_as_uint(inv_step));
+        uint32_t al[4], ah[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            al[m] = a_addr[m];
+            ah[m] = a_addr[m] + 2u * (TILE_UNITS * 16);
+        }
+        const uint64_t st_base = (uint64_t)(uintptr_t)gm_out;
+        const uint64_t st_bytes = (uint64_t)((G.n_rows + 31) / 32) * (RR_FLT_MAXQ * 4);
+        u32x4 st_rsrc;
+        st_rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)st_base);
+        st_rsrc.y = __builtin_amdgcn_readfirstlane((uint32_t)(st_base >> 32) & 0xFFFFu);
+        st_rsrc.z = (uint32_t)(st_bytes < 0xFFFFE000ull ? st_bytes : 0xFFFFE000ull);
+        st_rsrc.w = 0x00020000u;
+        const int64_t T = m1 - m0;                                      // M-tiles of this run
+        const int64_t full = G.n_rows / 32 - m0 < T ? G.n_rows / 32 - m0 : T;   // M-tiles [0, full) are whole
+        const int64_t cg2 = 2 * G.tiles_per_group;                     // M-tiles per selection group (a multiple of 4: rr_fltq_geom)
+        int64_t it = 0;
+        while (it < T) {
+            int64_t n_it = 0;
+            if (it >= 5 && (it & 3) == 1 && (cg2 & 3) == 0) {
+                // bodies it .. it + 4 n - 1: whole M-tiles; only the LAST one (it = 0 mod 4) may be a group's flush body
+                const int64_t flush = (it + cg2 - 1) / cg2 * cg2;       // next body whose end closes a group
+                int64_t end = flush + 1 < full ? flush + 1 : full;
+                if (end > T) end = T;
+                n_it = (end - it) / 4;
+            }
+            if (n_it > 0) {
+                // LDS-DMA resource: rows of this wave's row group of M-tile it + 3; num_records = bytes to the matrix's end
+                const int64_t first_row = (m0 + it + 3) * 32 + 8 * wu;
+                const uint64_t ld_base = (uint64_t)(uintptr_t)mat + (uint64_t)first_row * 768u;
+                const int64_t left = (G.n_rows - first_row) * 768;
+                u32x4 ld_rsrc;
+                ld_rsrc.x = __builtin_amdgcn_readfirstlane((uint32_t)ld_base);
+                ld_rsrc.y = __builtin_amdgcn_readfirstlane((uint32_t)(ld_base >> 32) & 0xFFFFu);
+                ld_rsrc.z = __builtin_amdgcn_readfirstlane((uint32_t)(left <= 0 ? 0 : left < 0x7FFFFFFFll ? left : 0x7FFFFFFFll));
+                ld_rsrc.w = 0x00020000u;
+                uint32_t st_soff = __builtin_amdgcn_readfirstlane((uint32_t)((m0 + it - 2) * (RR_FLT_MAXQ * 4)));
+                uint32_t loops = __builtin_amdgcn_readfirstlane((uint32_t)n_it);
+                // (the compiler moves the accumulators into / out of the loop's pinned registers with plain copies and does not
+                //  know that MFMAs -- inline asm to it -- wrote them: the matrix pipe must have drained on both sides; the
+                //  loop ends with its own s_nops, in front of the copies out)
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+#include "rr_fltq_loop.inc"
+                it += 4 * n_it;
+                finish_tile(m0 + it - 2);                               // (flushes only where that M-tile closes a group)
+            } else {
+                if (it & 1) body(std::integral_constant<int, 1>{}, m0 + it);
+                else body(std::integral_constant<int, 0>{}, m0 + it);
+                ++it;
+            }
+        }
+    } else {
     for (int64_t mt = m0; mt < m1; mt += 2) {
         body(std::integral_constant<int, 0>{}, mt);
         body(std::integral_constant<int, 1>{}, mt + 1);
+    }
+    }
+    if (DBG & 256) {
+#pragma unroll
+        for (int i = 0; i < 4 * F; ++i) asm volatile("" :: "v"(acc16[i / (2 * F)][(i / 2) % F][i & 1]));
     }
     // tail: the last M-tile (set 1) has its epilogue to run
     if constexpr (F == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
@@ -1182,6 +1270,7 @@ static rr_scan_geom rr_fltq_geom(rr_index* ix) {
     G.gpw = RR_MAX_SCAN_WAVES / G.n_waves < 32 ? (RR_MAX_SCAN_WAVES / G.n_waves < 1 ? 1 : RR_MAX_SCAN_WAVES / G.n_waves) : 32;
     if (G.gpw > G.tiles_per_wave) G.gpw = (int32_t)G.tiles_per_wave;
     G.tiles_per_group = (G.tiles_per_wave + G.gpw - 1) / G.gpw;
+    G.tiles_per_group += G.tiles_per_group & 1;       // even: a group closes on a multiple of four M-tiles (the unrolled loop)
     G.gpw = (int32_t)((G.tiles_per_wave + G.tiles_per_group - 1) / G.tiles_per_group);
     return G;
 }
@@ -1389,14 +1478,19 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
         const int slot = rr_scan_events_begin(ix, st);
         rr_scan_note(ix, 5, 9, nq_a + nq_b, 1, 2);
         static const bool w8 = getenv("RR_FLTQ_W8") != nullptr;
+        static const bool noasm = getenv("RR_FLTQ_NOASM") != nullptr;    // the C++ bodies everywhere (A/B)
         if (w8)
             hipLaunchKernelGGL((rr_scan_fltq<0, 8>), dim3(G.n_waves), dim3(512), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
                                reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
                                rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
+        else if (noasm)
+            hipLaunchKernelGGL((rr_scan_fltq<0>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+                               reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
+                               rr_flt_mmax_set_stride(G));
         else
-        hipLaunchKernelGGL((rr_scan_fltq<0>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
-                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
-                           rr_flt_mmax_set_stride(G));
+            hipLaunchKernelGGL((rr_scan_fltq<0, 4, true>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+                               reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
+                               rr_flt_mmax_set_stride(G));
         rr_scan_events_end(ix, slot, st);
         RR_HIP_TRY(hipGetLastError());
     } else if (dual) {
@@ -1484,6 +1578,8 @@ int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t
              : rr_dense_chunk_flt_t<4, false, false>(ix, m, d_q, nq, pool, d_rows, d_scores, nb, st, ph);
 }
 
+#ifdef RR_DEBUG_HARNESS
+#include "rr_debug.h"
 // Timing-only ablations of the 128-query fp32 filter scan (tools/flt_ablate.py).  Garbage in the scratch afterwards.
 template <int DBG, bool PLANE = false>
 static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
@@ -1538,6 +1634,97 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     return total / reps;
 }
 
+template <int DBG>
+static float rr_debug_time_fltq(rr_index* ix, hipStream_t st, int reps) {
+    if (!ix->shadow_valid) return -1.f;
+    const rr_scan_geom G = rr_fltq_geom(ix);
+    unsigned long long* d_st = nullptr;
+    if (hipMalloc((void**)&d_st, sizeof(unsigned long long) * 16 * 1024) != hipSuccess) return -1.f;
+    hipMemset(d_st, 0, sizeof(unsigned long long) * 16 * 1024);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float total = 0.f;
+    for (int r = 0; r < reps + 1; ++r) {
+        hipEventRecord(e0, st);
+        hipLaunchKernelGGL((rr_scan_fltq<DBG>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
+                           reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128, 128,
+                           rr_flt_mmax_set_stride(G), d_st);
+        hipEventRecord(e1, st);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (r) total += ms;
+    }
+    if (DBG & 128) {
+        std::vector<unsigned long long> hst((size_t)16 * G.n_waves);
+        hipMemcpy(hst.data(), d_st, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double sum[4] = {0, 0, 0, 0};
+        for (size_t k = 0; k < hst.size(); ++k) sum[k & 3] += (double)hst[k];
+        const double tiles = (double)((G.n_rows + 31) / 32) * 4;       // every wave of a workgroup walks every M-tile of its run
+        fprintf(stderr, "[fltq stamps %d] per M-tile and wave, shader cycles: wait + barrier %.0f, MFMA loop %.0f, epilogue + DMA issue %.0f; "
+                        "tile loop per wave %.0f\n", DBG & ~128, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / (4.0 * G.n_waves));
+    }
+    hipFree(d_st); hipEventDestroy(e0); hipEventDestroy(e1);
+    return total / reps;
+}
+
+// The hand-scheduled loop against the C++ bodies: both kernels scan the plane with the planes / bounds the last 256-query
+// search left in the scratch; every tile word and every group maximum of both query sets must come out bit for bit the
+// same.  out[0] = tile words that differ, out[1] = group maxima that differ, out[2] = words compared, out[3] = groups.
+extern "C" int rr_debug_fltq_compare(rr_index* ix, int64_t* out) {
+    RR_REQUIRE(ix && out && ix->shadow_valid && ix->scratch_q >= 64, "run a 256-query search on an fp32 index first");
+    std::lock_guard<std::mutex> lock(ix->mu);
+    hipStream_t st = nullptr;
+    const rr_scan_geom G = rr_fltq_geom(ix);
+    const size_t words = (size_t)2 * rr_flt_mmax_set_stride(G), groups = (size_t)2 * rr_flt_smax_set_stride();
+    std::vector<uint32_t> w[2], g[2];
+    for (int v = 0; v < 2; ++v) {
+        RR_HIP_TRY(hipMemsetAsync(ix->d_gmax, 0xA5, words * 4, st));
+        RR_HIP_TRY(hipMemsetAsync(ix->d_smax, 0xA5, groups * 4, st));
+        if (v == 0)
+            hipLaunchKernelGGL((rr_scan_fltq<0>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
+                               reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128, 128,
+                               rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
+        else
+            hipLaunchKernelGGL((rr_scan_fltq<0, 4, true>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
+                               reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128, 128,
+                               rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
+        RR_HIP_TRY(hipGetLastError());
+        w[v].resize(words);
+        g[v].resize(groups);
+        RR_HIP_TRY(hipMemcpy(w[v].data(), ix->d_gmax, words * 4, hipMemcpyDeviceToHost));
+        RR_HIP_TRY(hipMemcpy(g[v].data(), ix->d_smax, groups * 4, hipMemcpyDeviceToHost));
+    }
+    int64_t dw = 0, dg = 0, first = -1;
+    for (size_t i = 0; i < words; ++i)
+        if (w[0][i] != w[1][i]) {
+            if (first < 0) first = (int64_t)i;
+            ++dw;
+        }
+    for (size_t i = 0; i < groups; ++i) dg += g[0][i] != g[1][i];
+    out[0] = dw; out[1] = dg; out[2] = (int64_t)words; out[3] = (int64_t)groups; out[4] = first;
+    out[5] = first >= 0 ? w[0][first] : 0; out[6] = first >= 0 ? w[1][first] : 0;
+    if (dw && getenv("RR_DEBUG_FLTQ_DIFFS")) {          // where the words differ: by body of the unrolled loop, query, bit field
+        int64_t by_body[4] = {0, 0, 0, 0}, by_nib[8] = {0}, by_q32[4] = {0}, shown = 0;
+        const size_t per_set = words / 2;
+        for (size_t i = 0; i < words; ++i) {
+            if (w[0][i] == w[1][i]) continue;
+            const size_t j = i % per_set, tile = j / RR_FLT_MAXQ, q = j % RR_FLT_MAXQ;
+            const int64_t it = (int64_t)(tile % (2 * G.tiles_per_wave));
+            by_body[it & 3]++;
+            by_q32[q / 32]++;
+            const uint32_t x = w[0][i] ^ w[1][i];
+            for (int n = 0; n < 8; ++n) by_nib[n] += ((x >> (4 * n)) & 15u) != 0;
+            if (shown++ < 24) fprintf(stderr, "  set %d tile %zu (in run %lld) query %zu: %08x vs %08x\n", (int)(i / per_set), tile, (long long)it, q, w[0][i], w[1][i]);
+        }
+        fprintf(stderr, "  by (tile in run) & 3: %lld %lld %lld %lld; by query / 32: %lld %lld %lld %lld; by nibble 0..7: %lld %lld %lld %lld %lld %lld %lld %lld\n",
+                (long long)by_body[0], (long long)by_body[1], (long long)by_body[2], (long long)by_body[3], (long long)by_q32[0], (long long)by_q32[1],
+                (long long)by_q32[2], (long long)by_q32[3], (long long)by_nib[0], (long long)by_nib[1], (long long)by_nib[2], (long long)by_nib[3],
+                (long long)by_nib[4], (long long)by_nib[5], (long long)by_nib[6], (long long)by_nib[7]);
+    }
+    return RR_OK;
+}
+
 extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float* out_ms) {
     RR_REQUIRE(ix && out_ms && ix->dtype == RR_DTYPE_F32 && ix->dim_pad == 384, "fp32 index of dim 384 expected");
     RR_REQUIRE(ix->scratch_q >= 64, "run a batched search first (allocates the scratch)");
@@ -1578,34 +1765,32 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
             *out_ms = rr_debug_time_flt<192, true>(ix, st, reps);
             break;
         // 400 (16x16x32 kernel only; wrong results): stamped, cached, without the B-fragment reads
-        case 600: {       // rr_scan_fltq stamped (a 256-query search must have run: planes of both sets, scratch)
+        // 2000 + bits: rr_scan_fltq with in-kernel stamps, 1000 + bits: without (a 256-query search must have run: planes of
+        // both sets, scratch).  bits: 1 no LDS-DMA in the loop, 2 no epilogue pieces / stores, 4 no vmcnt wait + barrier, 8 no A
+        // reads in the loop, 64 pieces from cache-resident rows, 256 16x16x32 MFMAs (same MACs), 512 epilogue: tile maxima only
+#define RR_FLTQ_CASE(b) case 2000 + (b): *out_ms = rr_debug_time_fltq<128 | (b)>(ix, st, reps); break; \
+                        case 1000 + (b): *out_ms = rr_debug_time_fltq<(b)>(ix, st, reps); break;
+        RR_FLTQ_CASE(0) RR_FLTQ_CASE(1) RR_FLTQ_CASE(2) RR_FLTQ_CASE(3) RR_FLTQ_CASE(7) RR_FLTQ_CASE(15) RR_FLTQ_CASE(64) RR_FLTQ_CASE(66)
+        RR_FLTQ_CASE(256 + 3) RR_FLTQ_CASE(256 + 7) RR_FLTQ_CASE(256 + 15) RR_FLTQ_CASE(512) RR_FLTQ_CASE(512 + 1)
+#undef RR_FLTQ_CASE
+        case 3000: {      // the hand-scheduled loop (the product's default 256-query kernel), timed like the variants above
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
             const rr_scan_geom G = rr_fltq_geom(ix);
-            unsigned long long* d_st = nullptr;
-            RR_HIP_TRY(hipMalloc((void**)&d_st, sizeof(unsigned long long) * 16 * 1024));
-            RR_HIP_TRY(hipMemset(d_st, 0, sizeof(unsigned long long) * 16 * 1024));
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
             float total = 0.f;
             for (int r = 0; r < reps + 1; ++r) {
                 hipEventRecord(e0, st);
-                hipLaunchKernelGGL((rr_scan_fltq<128>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
+                hipLaunchKernelGGL((rr_scan_fltq<0, 4, true>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
                                    reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128, 128,
-                                   rr_flt_mmax_set_stride(G), d_st);
+                                   rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
                 hipEventRecord(e1, st);
                 hipEventSynchronize(e1);
                 float ms = 0.f;
                 hipEventElapsedTime(&ms, e0, e1);
                 if (r) total += ms;
             }
-            std::vector<unsigned long long> hst((size_t)16 * G.n_waves);
-            hipMemcpy(hst.data(), d_st, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-            hipFree(d_st); hipEventDestroy(e0); hipEventDestroy(e1);
-            double sum[4] = {0, 0, 0, 0};
-            for (size_t k = 0; k < hst.size(); ++k) sum[k & 3] += (double)hst[k];
-            const double tiles = (double)((G.n_rows + 31) / 32) * 4;       // every wave of a workgroup walks every M-tile of its run
-            fprintf(stderr, "[fltq stamps] per M-tile and wave, shader cycles: wait + barrier %.0f, MFMA loop %.0f, epilogue + DMA issue %.0f; "
-                            "tile loop per wave %.0f\n", sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / (4.0 * G.n_waves));
+            hipEventDestroy(e0); hipEventDestroy(e1);
             *out_ms = total / reps;
             break;
         }
@@ -1621,3 +1806,4 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
+#endif  // RR_DEBUG_HARNESS

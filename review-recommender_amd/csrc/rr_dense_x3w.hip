@@ -519,6 +519,8 @@ int rr_dense_chunk_x3w(rr_index* ix, const float* d_q, int nq, int pool, int64_t
              : rr_dense_chunk_x3w_t<2, false>(ix, d_q, nq, pool, d_rows, d_scores, st);
 }
 
+#ifdef RR_DEBUG_HARNESS
+#include "rr_debug.h"
 // Timing-only ablations of the fp32 wide scan at 64 queries (tools/x3w_ablate.py): runs variant `dbg`
 // `reps` times and returns the mean kernel time.  The scores it leaves behind are garbage.
 template <int DBG>
@@ -591,3 +593,4 @@ extern "C" int rr_debug_scan_x3w(rr_index* ix, int32_t dbg, int32_t reps, float*
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
+#endif  // RR_DEBUG_HARNESS

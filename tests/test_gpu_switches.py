@@ -48,7 +48,7 @@ def default_answer():
     return run_child({})
 
 
-@pytest.mark.parametrize("switch", ["RR_FLTQ_W8", "RR_NO_FLTQ", "RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR",
+@pytest.mark.parametrize("switch", ["RR_FLTQ_NOASM", "RR_FLTQ_W8", "RR_NO_FLTQ", "RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR",
                                     "RR_NO_PREFILTER", "RR_NO_SHADOW", "RR_NO_RESCORE_PLANE"])
 def test_switch_gives_the_default_answer(default_answer, switch):
     """rows AND scores bitwise: every filter path rescores its candidates with the single-query chain.  (RR_SCAN_EXACT is
@@ -60,3 +60,37 @@ def test_switch_gives_the_default_answer(default_answer, switch):
     got = run_child(env)
     for nq, (rows_h, sims_h) in default_answer.items():
         assert got[nq][0] == rows_h and got[nq][1] == sims_h, (switch, nq)
+
+
+def test_hand_scheduled_loop_writes_the_tile_words_of_the_cpp_bodies():
+    """rr_scan_fltq's steady-state loop is generated assembly (csrc/gen_fltq_loop.py); the C++ bodies it replaces stay in
+    the kernel for the ends of a run.  Both forms must leave the SAME tile words and group maxima, bit for bit, for both
+    query sets -- checked word by word through the ablation harness's library (librr_hip_dbg.so), in a child process."""
+    from review_recommender_amd.build import DEBUG_LIB_PATH
+    if not DEBUG_LIB_PATH.exists():
+        pytest.skip("librr_hip_dbg.so not built (python review-recommender_amd/build.py --debug)")
+    child = r"""
+import os, sys
+os.environ["RR_DEBUG_HARNESS"] = "1"
+sys.path.insert(0, %r)
+import ctypes as C
+import numpy as np, torch
+from review_recommender_amd import _lib
+from review_recommender_amd.index import ProductIndex
+lib = _lib.load()
+for n in (2_200_000, 1_000_003):
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    m = torch.randn((n, 384), device="cuda", generator=g); m /= m.norm(dim=1, keepdim=True)
+    ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=m.data_ptr(), keepalive=m)
+    ix.dense_topk(np.random.default_rng(6).standard_normal((256, 384)).astype(np.float32), 150)
+    out = (C.c_int64 * 8)()
+    _lib.check(lib.rr_debug_fltq_compare(ix.handle, out), "rr_debug_fltq_compare")
+    print("COMPARE", n, out[0], out[1], out[2], out[3])
+""" % ROOT
+    p = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l.split() for l in p.stdout.splitlines() if l.startswith("COMPARE ")]
+    assert len(lines) == 2
+    for _, n, dw, dg, words, groups in lines:
+        assert int(words) > 0 and int(groups) > 0
+        assert int(dw) == 0 and int(dg) == 0, (n, dw, dg)

@@ -1,6 +1,7 @@
 """Dev tool: what paces the 128-query fp32 filter scan?  python tools/flt_ablate.py [rows]
 Variant bits: 1 no epilogue, 2 no B-fragment LDS reads, 4 no MFMA, 8 no lane swaps / conversions."""
-import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys; os.environ["RR_DEBUG_HARNESS"] = "1"   # librr_hip_dbg.so (python review-recommender_amd/build.py --debug)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import numpy as np, torch
 from review_recommender_amd import _lib

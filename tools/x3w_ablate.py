@@ -1,6 +1,7 @@
 """Dev tool: what paces the 64-query fp32 batched scan?  python tools/x3w_ablate.py [rows]
 Variant bits: 1 no operand split, 2 no B-fragment LDS reads, 8 no lane swap, 16 in-kernel clock stamps."""
-import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys; os.environ["RR_DEBUG_HARNESS"] = "1"   # librr_hip_dbg.so (python review-recommender_amd/build.py --debug)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import numpy as np, torch
 from review_recommender_amd import _lib
