@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="matrix storage (bf16: BASELINE configs[3]; queries and arithmetic stay fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ce-precision", choices=["fp32", "bf16"], default="fp32",
+                    help="arithmetic of the K5 cross-encoder with --rerank-k: fp32 = the reference's (logits within 1e-5 of "
+                         "transformers), bf16 = the fast path (2.5e-2)")
     ap.add_argument("--rerank-k", type=int, default=0,
                     help="BASELINE config 5: cross-encoder rerank of the first RERANK_K pool rows per query (K5, seeded random "
                          "weights of the ms-marco-MiniLM-L-6 shape, synthetic product token ids built on the device); "
@@ -209,11 +212,11 @@ class SyntheticPairScorer:
     (seeded random weights: real ms-marco weights are not available offline).  The pool rows arrive on the host and the
     scores go back through it, as in the reference's flow (texts are host data)."""
 
-    def __init__(self, torch, dev, seed=7, chunk_tokens=1 << 20):
+    def __init__(self, torch, dev, seed=7, chunk_tokens=1 << 20, precision="fp32"):
         from review_recommender_amd import synth
         from review_recommender_amd.cross_encoder import CrossEncoder
         self.torch, self.dev, self.chunk = torch, dev, chunk_tokens
-        self.ce = CrossEncoder(synth.bert_state_dict(seed, n_layers=6, n_labels=1), device=dev.index)
+        self.ce = CrossEncoder(synth.bert_state_dict(seed, n_layers=6, n_labels=1), device=dev.index, precision=precision)
         self.pairs = 0
         self.tokens = 0
         self.ms = 0.0
@@ -289,7 +292,7 @@ def main():
 
     rerank_fn = None
     if args.rerank_k > 0:
-        rerank_fn = SyntheticPairScorer(torch, dev, seed=7)
+        rerank_fn = SyntheticPairScorer(torch, dev, seed=7, precision=args.ce_precision)
         w = FusionWeights(w_dense=0.4, w_bm25=0.2, w_rerank=0.3, w_prior=0.1, w_best=0.0, gate_penalty=1.0)
         pool = max(args.k, args.rerank_k, 150)
         pin_rows = torch.empty((args.batch, pool), dtype=torch.int64).pin_memory()
@@ -300,6 +303,7 @@ def main():
     # vs 0.69 ms per step, 10M rows 2.75 vs 2.72 ms: the cross-stream events cost more than the ~90 us of copies they
     # hide), so the default keeps every copy on the compute stream, in order.
     one_stream = os.environ.get("RR_BENCH_STREAMS") != "3"
+    kernel_copies = os.environ.get("RR_NO_KERNEL_COPY") is None      # (A/B: copy commands instead)
     out_stream = torch.cuda.Stream(device=dev)
     pins = [(pin_rows, pin_order, pin_final),
             (torch.empty_like(pin_rows).pin_memory(), torch.empty_like(pin_order).pin_memory(),
@@ -310,6 +314,15 @@ def main():
     def step(i):
         q_pin, terms = qsets[i % len(qsets)]
         cur = torch.cuda.current_stream(dev)
+        if one_stream and kernel_copies:
+            # H2D: K1's first kernel reads the pinned query vectors over PCIe itself; the token ids go through the
+            # searcher's pinned staging ring and one copy kernel (inside search); D2H: ONE kernel writes rows / order /
+            # final scores into the pinned answer buffers (rr_copy_segments_dev) -- the same bytes cross PCIe inside the
+            # step, without the fixed latency of five copy commands
+            rows, cols, order = sharded.search_batch_dev(q_pin, terms, args.k, w, rerank_k=args.rerank_k, rerank_fn=rerank_fn)
+            p_rows, p_order, p_final = pins[0]
+            sharded.s.copy_segments([(p_rows, rows), (p_order, order), (p_final, cols[:, 7, :])])
+            return
         if one_stream:
             q = q_dev[i % 2]
             q.copy_(q_pin, non_blocking=True)                    # H2D: query vectors (token ids: inside search)
@@ -397,6 +410,7 @@ def main():
     # the same filter scan with ONE query set per launch (128 queries per pass over the stream): the HBM-bound form of
     # the kernel -- the two-set launch above reads the stream once for 256 queries and is paced by the matrix side
     one_set = None
+    q_dev[0].copy_(qsets[0][0])                  # (the side measurements below search device-resident queries)
     if args.batch > 128 and info["queries_per_launch"] > 128:
         q128 = q_dev[0][:128].contiguous()
         for _ in range(2):
@@ -493,7 +507,7 @@ def main():
             out["metric"] = f"queries/sec, hybrid + cross-encoder rerank top-{args.rerank_k} -> top-{args.k}"
             out["config"]["workload"] += (f"; rerank of the first {args.rerank_k} pool rows per query by the K5 cross-encoder "
                                           "(MiniLM-L6 shape, seeded weights, synthetic token ids 65..512 per pair)")
-            out["rerank"] = {"pairs_per_step": args.batch * args.rerank_k,
+            out["rerank"] = {"precision": args.ce_precision, "pairs_per_step": args.batch * args.rerank_k,
                              "mean_tokens_per_pair": round(rerank_fn.tokens / max(rerank_fn.pairs, 1), 1)}
         if world == 1 and not args.no_cpu_baseline and rerank_fn is None:
             out["cpu_baseline"] = cpu_baseline(torch, args, shard, qsets)

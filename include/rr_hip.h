@@ -213,6 +213,21 @@ int rr_index_gather_meta_dev(rr_index* ix, const int64_t* d_rows, int64_t n,
                              double* d_n_reviews, double* d_avg_stars, double* d_log1p_n,
                              void* stream);
 
+/* Kernel-driven copies: ONE launch moves up to RR_COPY_MAX_SEGS pitched segments (rows x row_bytes, each side with its
+ * own pitch) on `stream`.  Either side of a segment may be PINNED HOST memory that is mapped into the device's address
+ * space (hipHostMalloc, torch's pin_memory(): the host pointer is valid on the device): a batch's inputs (token ids)
+ * and its answer (rows / order / final scores: what the reference returns to its caller, app/app_product_search.py:312-317)
+ * then cross PCIe as the loads / stores of one kernel instead of as one copy command each.  In the same way
+ * rr_dense_topk_dev accepts mapped pinned host memory as `d_queries` (its first kernel reads the queries once).
+ * Not a product path of its own: the data movement in front of K1 / behind K3. */
+#define RR_COPY_MAX_SEGS 4
+typedef struct rr_copy_seg {
+    void* dst;
+    const void* src;
+    int64_t row_bytes, rows, dst_pitch, src_pitch;
+} rr_copy_seg;
+int rr_copy_segments_dev(const rr_copy_seg* segs, int32_t n_segs, int32_t device, void* stream);
+
 /* ------------------------------------------------------------ best review per candidate */
 
 typedef struct rr_reviews rr_reviews;
@@ -254,7 +269,14 @@ typedef struct rr_ce_config {
     int32_t vocab, max_pos, type_vocab;           /* embedding table sizes */
     int32_t n_labels;                             /* classifier outputs (1 for the reranker); 0 = no pooler / classifier */
     float ln_eps;                                 /* 1e-12 for BERT */
+    int32_t precision;                            /* RR_CE_PRECISION_BF16 (fast path) | RR_CE_PRECISION_F32 (the reference's arithmetic) */
 } rr_ce_config;
+/* RR_CE_PRECISION_BF16: Linear weights rounded once to bf16, bf16 MFMA operands, fp32 accumulation / residual / LayerNorm /
+ * softmax / GELU: logits within 2.5e-2 of the fp32 reference on O(1) weights.  RR_CE_PRECISION_F32: what the reference runs
+ * (fp32 torch, app/app_product_search.py:250-251, 277-278): fp32 weights and activations on the fp32-input matrix
+ * instructions, exact erf / exp: logits and embeddings within 1e-5 of `transformers` (tests/test_gpu_k5.py), ~10x the time. */
+#define RR_CE_PRECISION_BF16 0
+#define RR_CE_PRECISION_F32 1
 /* Weights: fp32 host arrays in the layout of a Hugging Face BERT state dict (Linear weights are [out][in]), in this order:
  *   0 word_embeddings [vocab][H]   1 position_embeddings [max_pos][H]   2 token_type_embeddings [type_vocab][H]
  *   3 embeddings.LayerNorm.weight  4 embeddings.LayerNorm.bias
@@ -262,7 +284,8 @@ typedef struct rr_ce_config {
  *     attention.output.dense.weight, .bias, attention.output.LayerNorm.weight, .bias,
  *     intermediate.dense.weight [FFN][H], .bias, output.dense.weight [H][FFN], .bias, output.LayerNorm.weight, .bias
  *   when n_labels > 0, four more: pooler.dense.weight [H][H], pooler.dense.bias, classifier.weight [n_labels][H], classifier.bias
- * Linear weights are rounded once to bf16 (nearest even) on the device; everything else stays fp32. */
+ * Linear weights are rounded once to bf16 (nearest even) on the device (RR_CE_PRECISION_F32 also keeps them as given);
+ * everything else stays fp32. */
 int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float* const* h_tensors, int32_t n_tensors, rr_ce** out);
 int rr_ce_destroy(rr_ce* ce);
 #define RR_CE_OUT_LOGITS 0   /* d_out [n_seqs][n_labels]: classifier(tanh(pooler([CLS]))), raw logits (no activation) */

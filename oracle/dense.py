@@ -35,7 +35,12 @@ def topk_reference_order(sims: np.ndarray, top_k: int) -> Tuple[np.ndarray, np.n
 
 def sims_float64(embeddings_matrix: np.ndarray, query_vector: np.ndarray) -> np.ndarray:
     """Float64 dot products: the rounding-free yardstick for tolerance checks."""
-    return embeddings_matrix.astype(np.float64) @ query_vector.astype(np.float64)
+    q64 = query_vector.astype(np.float64)
+    step = 1_000_000                 # (rows are independent: chunking bounds the float64 copy at 10M rows, same values)
+    if embeddings_matrix.shape[0] <= step:
+        return embeddings_matrix.astype(np.float64) @ q64
+    return np.concatenate([embeddings_matrix[s:s + step].astype(np.float64) @ q64
+                           for s in range(0, embeddings_matrix.shape[0], step)])
 
 
 def round_to_bf16(x: np.ndarray) -> np.ndarray:

@@ -12,6 +12,12 @@ c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, 
 P = C.POINTER
 
 
+class CopySeg(C.Structure):
+    """struct rr_copy_seg (include/rr_hip.h)."""
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("row_bytes", C.c_int64), ("rows", C.c_int64),
+                ("dst_pitch", C.c_int64), ("src_pitch", C.c_int64)]
+
+
 class FuseParams(C.Structure):
     """struct rr_fuse_params (include/rr_hip.h)."""
     _fields_ = [("w_dense", c_f64), ("w_bm25", c_f64), ("w_rerank", c_f64),
@@ -26,7 +32,7 @@ class CEConfig(C.Structure):
     """struct rr_ce_config (include/rr_hip.h)."""
     _fields_ = [("hidden", c_i32), ("n_layers", c_i32), ("n_heads", c_i32), ("ffn", c_i32),
                 ("vocab", c_i32), ("max_pos", c_i32), ("type_vocab", c_i32), ("n_labels", c_i32),
-                ("ln_eps", c_f32)]
+                ("ln_eps", c_f32), ("precision", c_i32)]
 
 
 # name -> (restype, argtypes); every symbol include/rr_hip.h declares
@@ -63,6 +69,7 @@ PROTOTYPES = {
     "rr_fuse_topk_dev": (C.c_int, [c_vp, P(FuseParams), c_i32] + [c_vp] * 9 + [c_vp] * 3 + [c_vp]),
     "rr_fuse_topk": (C.c_int, [c_vp, P(FuseParams), c_i32] + [c_vp] * 9 + [c_vp] * 3),
     "rr_index_gather_meta_dev": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "rr_copy_segments_dev": (C.c_int, [c_vp, c_i32, c_i32, c_vp]),
     "rr_reviews_create": (C.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_f32, P(c_vp)]),
     "rr_reviews_destroy": (C.c_int, [c_vp]),
     "rr_reviews_best_dev": (C.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),

@@ -39,16 +39,27 @@ def hipcc_path() -> str:
     return exe
 
 
-def _headers():
-    return sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + [PKG_DIR.parent / "include" / "rr_hip.h"]
+def _headers(debug: bool = False):
+    incs = [p for p in sorted(CSRC.glob("*.inc")) if debug or p.name != "rr_fltq_loop_abl.inc"]
+    return sorted(CSRC.glob("*.h")) + incs + [PKG_DIR.parent / "include" / "rr_hip.h"]
 
 
-def check_generated() -> None:
-    """csrc/rr_fltq_loop.inc is generated (gen_fltq_loop.py) and committed: a stale copy must not build."""
+FLTQ_ABLATIONS = "128,1,2,3,4,8,64,66"      # tools/fltq_ablate.py variants 3000 + n (rr_dense_flt.hip: RR_FLTQA_CASE)
+
+
+def check_generated(debug: bool = False) -> None:
+    """csrc/rr_fltq_loop.inc is generated (gen_fltq_loop.py) and committed: a stale copy must not build.  The debug
+    harness's timing ablations of that loop (rr_fltq_loop_abl.inc) are generated on demand and not committed."""
     gen = subprocess.run([os.sys.executable, str(CSRC / "gen_fltq_loop.py")], capture_output=True, text=True, check=True)
     inc = CSRC / "rr_fltq_loop.inc"
     if not inc.exists() or inc.read_text() != gen.stdout:
         inc.write_text(gen.stdout)
+    if debug:
+        gen = subprocess.run([os.sys.executable, str(CSRC / "gen_fltq_loop.py"), "--abl", FLTQ_ABLATIONS],
+                             capture_output=True, text=True, check=True)
+        inc = CSRC / "rr_fltq_loop_abl.inc"
+        if not inc.exists() or inc.read_text() != gen.stdout:
+            inc.write_text(gen.stdout)
 
 
 def _digest(paths, extra: str = "") -> str:
@@ -64,11 +75,11 @@ def _flags(debug: bool):
 
 
 def _source_digest(src: str, debug: bool = False) -> str:
-    return _digest([CSRC / src] + _headers(), " ".join(_flags(debug)))
+    return _digest([CSRC / src] + _headers(debug), " ".join(_flags(debug)))
 
 
 def library_digest(debug: bool = False) -> str:
-    return _digest([CSRC / s for s in SOURCES] + _headers(), " ".join(_flags(debug)))
+    return _digest([CSRC / s for s in SOURCES] + _headers(debug), " ".join(_flags(debug)))
 
 
 def needs_build(debug: bool = False) -> bool:
@@ -99,7 +110,7 @@ def build_library(force: bool = False, verbose: bool = False, jobs: int = 0, deb
     """debug=True: librr_hip_dbg.so = the same sources + the ablation harness (-DRR_DEBUG_HARNESS), for tools/ only."""
     lib_path, build_id, obj_dir = ((DEBUG_LIB_PATH, DEBUG_BUILD_ID, DEBUG_OBJ_DIR) if debug
                                    else (LIB_PATH, BUILD_ID, OBJ_DIR))
-    check_generated()
+    check_generated(debug)
     if not force and not needs_build(debug):
         return lib_path
     obj_dir.mkdir(exist_ok=True)

@@ -7,8 +7,9 @@ Drop-ins for the two sentence-transformers objects the reference holds:
   SentenceTransformer(EMB_MODEL).encode([query], normalize_embeddings=True) -> (n, 384) float32
       app/app_product_search.py:53-69,250-251; app/test.py:91-94,232
 
-Both run csrc/rr_ce.hip (bf16 MFMA GEMMs + attention, fp32 residual stream) through the C ABI
-(rr_ce_create / rr_ce_forward_dev).  Weights come from a local state dict (Hugging Face BERT names: a
+Both run csrc/rr_ce.hip through the C ABI (rr_ce_create / rr_ce_forward_dev), in one of two precisions: "fp32" (default:
+the reference's arithmetic, fp32 operands on the fp32-input matrix instructions, within 1e-5 of `transformers`) or "bf16"
+(the fast path: bf16 MFMA GEMMs + attention, fp32 residual stream).  Weights come from a local state dict (Hugging Face BERT names: a
 `model.safetensors` / `pytorch_model.bin` directory, or a dict of arrays); text is tokenised by
 wordpiece.WordPieceTokenizer from a local vocab.txt.  Without a vocabulary on disk the pre-tokenised entry
 points (`predict_ids`, `encode_ids`) take token-id sequences directly.  Nothing is ever fetched.
@@ -30,6 +31,7 @@ from . import _lib
 from .wordpiece import WordPieceTokenizer
 
 OUT_LOGITS, OUT_CLS, OUT_HIDDEN = 0, 1, 2       # RR_CE_OUT_*
+PRECISIONS = {"bf16": 0, "fp32": 1}              # RR_CE_PRECISION_*
 HIDDEN, HEADS, FFN = 384, 12, 1536
 
 _LAYER_KEYS = ("attention.self.query.weight", "attention.self.query.bias", "attention.self.key.weight",
@@ -56,7 +58,13 @@ class BertEncoderGPU:
     """A BERT encoder (+ optional sequence-classification head) resident on one GPU."""
 
     def __init__(self, state_dict: Dict, *, device: int = 0, ln_eps: float = 1e-12, with_head: bool = True,
-                 max_tokens_per_call: int = 131_072):
+                 max_tokens_per_call: int = 131_072, precision: str = "fp32"):
+        """``precision``: "fp32" = the reference's arithmetic (fp32 weights and activations on the fp32-input matrix
+        instructions: logits / embeddings within 1e-5 of `transformers`), "bf16" = the fast path (bf16 operands, fp32
+        accumulation: 2.5e-2 on O(1) logits, ~10x the throughput).  include/rr_hip.h: RR_CE_PRECISION_*."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self.precision = precision
         sd = state_dict
         p = _find_prefix(sd)
         word = _np(sd[p + "embeddings.word_embeddings.weight"])
@@ -84,7 +92,8 @@ class BertEncoderGPU:
         self.n_layers, self.n_labels, self.vocab, self.max_pos = n_layers, n_labels, word.shape[0], pos.shape[0]
         self.type_vocab, self.device = typ.shape[0], device
         self.max_tokens_per_call = int(max_tokens_per_call)
-        cfg = _lib.CEConfig(HIDDEN, n_layers, HEADS, FFN, self.vocab, self.max_pos, self.type_vocab, n_labels, ln_eps)
+        cfg = _lib.CEConfig(HIDDEN, n_layers, HEADS, FFN, self.vocab, self.max_pos, self.type_vocab, n_labels, ln_eps,
+                            PRECISIONS[precision])
         ptrs = (C.c_void_p * len(tensors))(*[t.ctypes.data for t in tensors])
         h = C.c_void_p()
         _lib.check(_lib.load().rr_ce_create(device, C.byref(cfg), ptrs, len(tensors), C.byref(h)), "rr_ce_create")
@@ -214,8 +223,10 @@ class CrossEncoder:
     show_progress_bar=False)` -> float32 (len(pairs),) for a single-label model."""
 
     def __init__(self, state_dict: Dict, tokenizer: Optional[WordPieceTokenizer] = None, *, device: int = 0,
-                 max_length: int = 512, activation: Optional[str] = None, ln_eps: float = 1e-12):
-        self.model = BertEncoderGPU(state_dict, device=device, ln_eps=ln_eps, with_head=True)
+                 max_length: int = 512, activation: Optional[str] = None, ln_eps: float = 1e-12, precision: str = "fp32"):
+        """``precision`` "fp32" (default: the reference reranks in fp32, app/app_product_search.py:277-278) or "bf16"
+        (fast path, logits within 2.5e-2): see BertEncoderGPU."""
+        self.model = BertEncoderGPU(state_dict, device=device, ln_eps=ln_eps, with_head=True, precision=precision)
         if self.model.n_labels < 1:
             raise ValueError("the state dict has no pooler / classifier: not a sequence-classification checkpoint")
         self.tokenizer = tokenizer
@@ -263,8 +274,10 @@ class QueryEncoder:
     (n, 384) float32; CLS pooling (bge-small-en-v1.5's pooling config)."""
 
     def __init__(self, state_dict: Dict, tokenizer: Optional[WordPieceTokenizer] = None, *, device: int = 0,
-                 max_length: int = 512, ln_eps: float = 1e-12):
-        self.model = BertEncoderGPU(state_dict, device=device, ln_eps=ln_eps, with_head=False)
+                 max_length: int = 512, ln_eps: float = 1e-12, precision: str = "fp32"):
+        """``precision`` "fp32" by default: the query vector feeds K1, whose answers are held to a 4e-7 tie band -- a bf16
+        encoder would move dense scores by ~2e-3 (one short sequence per query: the fp32 forward costs microseconds)."""
+        self.model = BertEncoderGPU(state_dict, device=device, ln_eps=ln_eps, with_head=False, precision=precision)
         self.tokenizer = tokenizer
         self.max_length = min(int(max_length), self.model.max_pos)
 

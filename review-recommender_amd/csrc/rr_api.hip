@@ -31,6 +31,91 @@ extern "C" int rr_device_count(int* out) {
 
 static size_t rr_elem_size(int dtype) { return dtype == RR_DTYPE_BF16 ? 2 : 4; }
 
+// ------------------------------------------------------------------ kernel-driven copies (include/rr_hip.h)
+// One launch moves up to RR_COPY_MAX_SEGS pitched segments; either side of a segment may be pinned host memory mapped
+// into the device's address space (hipHostMalloc / torch pin_memory: the host pointer is the device pointer).  A
+// batch's inputs and answers are a few hundred KB: as copy commands each of them costs 10 - 20 us of fixed latency on
+// the stream; as loads / stores of one kernel they cost their PCIe time (~15 us per 0.7 MB).
+struct rr_copy_args {
+    rr_copy_seg seg[RR_COPY_MAX_SEGS];
+};
+__global__ __launch_bounds__(256) void rr_copy_segments(rr_copy_args A) {
+    const rr_copy_seg sg = A.seg[blockIdx.y];
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (int64_t)gridDim.x * 256;
+    char* dst = static_cast<char*>(sg.dst);
+    const char* src = static_cast<const char*>(sg.src);
+    const uint64_t bits = (uint64_t)(uintptr_t)dst | (uint64_t)(uintptr_t)src | (uint64_t)sg.row_bytes | (uint64_t)sg.dst_pitch |
+                          (uint64_t)sg.src_pitch;
+    if ((bits & 15u) == 0) {
+        const int64_t per_row = sg.row_bytes / 16, n = per_row * sg.rows;
+        for (int64_t i = tid; i < n; i += nthreads) {
+            const int64_t r = i / per_row, c = i % per_row;
+            *reinterpret_cast<f32x4*>(dst + r * sg.dst_pitch + 16 * c) = *reinterpret_cast<const f32x4*>(src + r * sg.src_pitch + 16 * c);
+        }
+    } else if ((bits & 3u) == 0) {
+        const int64_t per_row = sg.row_bytes / 4, n = per_row * sg.rows;
+        for (int64_t i = tid; i < n; i += nthreads) {
+            const int64_t r = i / per_row, c = i % per_row;
+            *reinterpret_cast<uint32_t*>(dst + r * sg.dst_pitch + 4 * c) = *reinterpret_cast<const uint32_t*>(src + r * sg.src_pitch + 4 * c);
+        }
+    } else {
+        const int64_t n = sg.row_bytes * sg.rows;
+        for (int64_t i = tid; i < n; i += nthreads) {
+            const int64_t r = i / sg.row_bytes, c = i % sg.row_bytes;
+            dst[r * sg.dst_pitch + c] = src[r * sg.src_pitch + c];
+        }
+    }
+}
+
+// The address a kernel may use for `p`: device memory as it is; pinned host memory through its mapping (on this stack the
+// same value, but the runtime is the one to say so); anything else (pageable host memory) is refused.
+int rr_device_visible(const void* p, const void** out, const char* what) {
+    hipPointerAttribute_t at;
+    const hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("%s: %p is neither device memory nor pinned (mapped) host memory", what, p);
+        return RR_E_INVALID;
+    }
+    if (at.type == hipMemoryTypeHost) {
+        RR_REQUIRE(at.devicePointer != nullptr, "%s: pinned host memory %p is not mapped into the device", what, p);
+        *out = static_cast<const char*>(at.devicePointer);
+        return RR_OK;
+    }
+    RR_REQUIRE(at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeUnified,
+               "%s: %p is pageable host memory (pin it, or copy it to the device first)", what, p);
+    *out = p;
+    return RR_OK;
+}
+
+extern "C" int rr_copy_segments_dev(const rr_copy_seg* segs, int32_t n_segs, int32_t device, void* stream) {
+    RR_REQUIRE(segs && n_segs >= 1 && n_segs <= RR_COPY_MAX_SEGS, "rr_copy_segments_dev: 1 .. %d segments", RR_COPY_MAX_SEGS);
+    rr_copy_args A;
+    int64_t most = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const rr_copy_seg& g = segs[i];
+        RR_REQUIRE(g.dst && g.src && g.rows >= 0 && g.row_bytes >= 0 && g.dst_pitch >= g.row_bytes && g.src_pitch >= g.row_bytes,
+                   "rr_copy_segments_dev: segment %d: NULL pointer, negative size or a pitch below row_bytes", i);
+        A.seg[i] = g;
+        const void* vis = nullptr;
+        int rc = rr_device_visible(g.dst, &vis, "rr_copy_segments_dev (dst)");
+        if (rc) return rc;
+        A.seg[i].dst = const_cast<void*>(vis);
+        rc = rr_device_visible(g.src, &vis, "rr_copy_segments_dev (src)");
+        if (rc) return rc;
+        A.seg[i].src = vis;
+        const int64_t bytes = g.rows * g.row_bytes;
+        most = bytes > most ? bytes : most;
+    }
+    if (most == 0) return RR_OK;
+    RR_HIP_TRY(hipSetDevice(device));
+    int64_t blocks = (most / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 512 ? 512 : blocks;
+    hipLaunchKernelGGL(rr_copy_segments, dim3((unsigned)blocks, (unsigned)n_segs), dim3(256), 0, (hipStream_t)stream, A);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
 extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim, int32_t dtype,
                                int32_t device, int64_t row_offset, rr_index** out) {
     RR_REQUIRE(out, "rr_index_create: NULL out");

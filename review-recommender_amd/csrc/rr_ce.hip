@@ -746,12 +746,159 @@ __global__ void ce_to_bf16(const float* __restrict__ src, unsigned short* __rest
     if (i < n) dst[i] = ce_bf16_bits(src[i]);
 }
 
+
+// ------------------------------------------------------------------ reference-precision mode (RR_CE_PRECISION_F32)
+// The reference runs both encoders in fp32 torch (app/app_product_search.py:250-251, 277-278).  The kernels above multiply
+// in bf16 (2.5e-2 on logits of O(1)): the fast path.  This mode keeps every operand fp32 end to end -- fp32 weights, fp32
+// activations, the fp32-input matrix instruction v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation: the chip's
+// vector-rate matrix path, 157 TF/s), exact erf / exp / tanh of the device library -- so that logits and embeddings agree
+// with the `transformers` fixtures to fp32 rounding (1e-5, tests/test_gpu_k5.py).  Plain tiling, no fusion: this is the
+// parity mode, ~10x the time of the bf16 path.
+typedef float f32x16r __attribute__((ext_vector_type(16)));
+
+// out[M][N] = A[M][K] W[N][K]^T + bias (+ exact GELU); A, W, out fp32 row-major; N % 128 == 0, K % 8 == 0.
+// Workgroup = 4 waves (2 x 2), 128 x 128 outputs, wave = 64 x 64 = 2 x 2 MFMA tiles; K tiles of 8 through LDS, stored
+// k-major ([k][row], rows padded to 132 floats: conflict-free for the ds_write_b32 of the staging and the ds_read_b32 of
+// the operands).  MFMA operands: A lane l = row (l & 31), k = l >> 5; B lane l = column (l & 31), k = l >> 5; C register
+// 4 g + i = row 8 g + 4 (l >> 5) + i, column l & 31.
+#define CE_F32_LD 132
+template <bool GELU>
+__global__ __launch_bounds__(256) void ce_gemm_f32(const float* __restrict__ A, const float* __restrict__ W,
+                                                   const float* __restrict__ bias, int M, int N, int K,
+                                                   float* __restrict__ out) {
+    __shared__ float As[8 * CE_F32_LD], Ws[8 * CE_F32_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int srow = tid >> 1, skq = tid & 1;                 // staging: row of the tile, which float4 of its 8 k
+    int arow = m0 + srow;
+    arow = arow < M ? arow : M - 1;                           // (rows past the end: clamped loads, masked stores)
+    const float* ap = A + (int64_t)arow * K + 4 * skq;
+    const float* wp = W + (int64_t)(n0 + srow) * K + 4 * skq;
+    f32x16r acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int r = lane & 31, kh = lane >> 5;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k0);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + k0);
+        __syncthreads();                                      // the previous tile has been read
+        As[(4 * skq + 0) * CE_F32_LD + srow] = av.x; As[(4 * skq + 1) * CE_F32_LD + srow] = av.y;
+        As[(4 * skq + 2) * CE_F32_LD + srow] = av.z; As[(4 * skq + 3) * CE_F32_LD + srow] = av.w;
+        Ws[(4 * skq + 0) * CE_F32_LD + srow] = wv.x; Ws[(4 * skq + 1) * CE_F32_LD + srow] = wv.y;
+        Ws[(4 * skq + 2) * CE_F32_LD + srow] = wv.z; Ws[(4 * skq + 3) * CE_F32_LD + srow] = wv.w;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {                      // k pairs: lanes < 32 hold k = 2 kk, lanes >= 32 k = 2 kk + 1
+            const int kr = (2 * kk + kh) * CE_F32_LD;
+            const float a0 = As[kr + wm + r], a1 = As[kr + wm + 32 + r];
+            const float b0 = Ws[kr + wn + r], b1 = Ws[kr + wn + 32 + r];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + r;
+            const float bv = bias[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * kh + (e & 3);
+                if (row < M) {
+                    float x = acc[i][j][e] + bv;
+                    if (GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));      // gelu(x) = x Phi(x), erf form (HF "gelu")
+                    out[(int64_t)row * N + col] = x;
+                }
+            }
+        }
+}
+
+// h32[t] = LayerNorm(y[t] + h32[t]) * g + b  (BertSelfOutput / BertOutput: dense -> + residual -> LayerNorm), one wave per token
+__global__ __launch_bounds__(256) void ce_add_ln_f32(const float* __restrict__ y, float* __restrict__ h32, int T,
+                                                     const float* __restrict__ g, const float* __restrict__ b, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    float x[6];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        x[i] = y[(int64_t)t * CE_H + c] + h32[(int64_t)t * CE_H + c];
+        s += x[i];
+    }
+    const float mean = ce_wave_sum(s) * (1.f / CE_H);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const float d = x[i] - mean; v += d * d; }
+    const float rstd = 1.0f / sqrtf(ce_wave_sum(v) * (1.f / CE_H) + eps);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = lane + 64 * i;
+        h32[(int64_t)t * CE_H + c] = (x[i] - mean) * rstd * g[c] + b[c];
+    }
+}
+
+// softmax(Q K^T / sqrt(32)) V of one (sequence, head), fp32: K and V of the head in LDS, one query per thread (its 32
+// dims and 32 outputs in registers), exact two-pass softmax (maximum, then exp and sums).
+__global__ __launch_bounds__(256) void ce_attention_f32(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                        float* __restrict__ ctx, float scale) {
+    extern __shared__ float kv[];                             // K [S][32], V [S][32]
+    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    float* Ks = kv;
+    float* Vs = kv + (size_t)S * CE_HD;
+    for (int i = tid; i < S * (CE_HD / 4); i += 256) {
+        const int j = i / (CE_HD / 4), c = i % (CE_HD / 4);
+        const float* row = qkv + (int64_t)(t0 + j) * (3 * CE_H) + head * CE_HD + 4 * c;
+        *reinterpret_cast<f32x4*>(Ks + j * CE_HD + 4 * c) = *reinterpret_cast<const f32x4*>(row + CE_H);
+        *reinterpret_cast<f32x4*>(Vs + j * CE_HD + 4 * c) = *reinterpret_cast<const f32x4*>(row + 2 * CE_H);
+    }
+    __syncthreads();
+    for (int qi = tid; qi < S; qi += 256) {
+        float q[CE_HD], o[CE_HD];
+        const float* qp = qkv + (int64_t)(t0 + qi) * (3 * CE_H) + head * CE_HD;
+#pragma unroll
+        for (int d = 0; d < CE_HD; ++d) { q[d] = qp[d]; o[d] = 0.f; }
+        float mx = -INFINITY;
+        for (int j = 0; j < S; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < CE_HD; ++d) s = __builtin_fmaf(q[d], Ks[j * CE_HD + d], s);
+            mx = fmaxf(mx, s * scale);
+        }
+        float l = 0.f;
+        for (int j = 0; j < S; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < CE_HD; ++d) s = __builtin_fmaf(q[d], Ks[j * CE_HD + d], s);
+            const float p = expf(s * scale - mx);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < CE_HD; ++d) o[d] = __builtin_fmaf(p, Vs[j * CE_HD + d], o[d]);
+        }
+        const float inv = 1.0f / l;
+        float* op = ctx + (int64_t)(t0 + qi) * CE_H + head * CE_HD;
+#pragma unroll
+        for (int d = 0; d < CE_HD; ++d) op[d] = o[d] * inv;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct rr_ce_layer {
     unsigned short *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;      // bf16 [N][K]
     unsigned short* w2p = nullptr;   // w2 with the columns of every 16-group in the fused FFN's accumulator-operand order
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+    float *wqkv32 = nullptr, *wo32 = nullptr, *w1_32 = nullptr, *w2_32 = nullptr;     // RR_CE_PRECISION_F32: the Linear weights as given
 };
 
 struct rr_ce {
@@ -768,6 +915,9 @@ struct rr_ce {
     int64_t cap_seqs = 0;
     float* h32c = nullptr;
     unsigned short *hbc = nullptr, *ctxc = nullptr, *interc = nullptr;
+    // RR_CE_PRECISION_F32: fp32 activations
+    int64_t cap32 = 0;
+    float *qkv32 = nullptr, *y32 = nullptr, *inter32 = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::mutex mu;
@@ -805,11 +955,13 @@ extern "C" int rr_ce_destroy(rr_ce* ce) {
             hipFree(L.wqkv); hipFree(L.wo); hipFree(L.w1); hipFree(L.w2); hipFree(L.w2p);
             hipFree(L.bqkv); hipFree(L.bo); hipFree(L.b1); hipFree(L.b2);
             hipFree(L.ln1_g); hipFree(L.ln1_b); hipFree(L.ln2_g); hipFree(L.ln2_b);
+            hipFree(L.wqkv32); hipFree(L.wo32); hipFree(L.w1_32); hipFree(L.w2_32);
         }
     delete[] ce->layers;
     hipFree(ce->wp); hipFree(ce->bp); hipFree(ce->wc); hipFree(ce->bc);
     hipFree(ce->h32); hipFree(ce->hb); hipFree(ce->qkv); hipFree(ce->ctx); hipFree(ce->inter);
     hipFree(ce->h32c); hipFree(ce->hbc); hipFree(ce->ctxc); hipFree(ce->interc);
+    hipFree(ce->qkv32); hipFree(ce->y32); hipFree(ce->inter32);
     if (ce->ev0) hipEventDestroy(ce->ev0);
     if (ce->ev1) hipEventDestroy(ce->ev1);
     delete ce;
@@ -832,6 +984,8 @@ extern "C" int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float
     const int want = 5 + 16 * cfg->n_layers + (cfg->n_labels > 0 ? 4 : 0);
     RR_REQUIRE(n_tensors == want, "rr_ce_create: %d tensors given, %d expected (include/rr_hip.h lists the order)",
                n_tensors, want);
+    RR_REQUIRE(cfg->precision == RR_CE_PRECISION_BF16 || cfg->precision == RR_CE_PRECISION_F32,
+               "rr_ce_create: unknown precision %d", cfg->precision);
     for (int i = 0; i < n_tensors; ++i) RR_REQUIRE(t[i], "rr_ce_create: tensor %d is NULL", i);
     RR_HIP_TRY(hipSetDevice(device));
     rr_ce* ce = new rr_ce();
@@ -877,6 +1031,17 @@ extern "C" int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float
             b16(L.w2p, perm.data(), H * F);
         }
         f32(&L.ln2_g, p[14], H); f32(&L.ln2_b, p[15], H);
+        if (cfg->precision == RR_CE_PRECISION_F32 && !rc) {
+            if (hipMalloc((void**)&L.wqkv32, sizeof(float) * 3 * H * H) != hipSuccess) rc = RR_E_NOMEM;
+            if (!rc) {
+                hipMemcpy(L.wqkv32, p[0], sizeof(float) * H * H, hipMemcpyHostToDevice);
+                hipMemcpy(L.wqkv32 + H * H, p[2], sizeof(float) * H * H, hipMemcpyHostToDevice);
+                hipMemcpy(L.wqkv32 + 2 * H * H, p[4], sizeof(float) * H * H, hipMemcpyHostToDevice);
+            }
+            f32(&L.wo32, p[6], H * H);
+            f32(&L.w1_32, p[10], F * H);
+            f32(&L.w2_32, p[12], H * F);
+        }
     }
     if (!rc && cfg->n_labels > 0) {
         const float* const* p = t + 5 + 16 * cfg->n_layers;
@@ -930,6 +1095,69 @@ static int ce_reserve_seqs(rr_ce* ce, int64_t seqs) {
 
 static size_t ce_attention_lds(int smax_pad) { return (size_t)smax_pad * CE_KS_LD * 2 + (size_t)32 * (smax_pad + 8) * 2; }
 
+// per-device one-time opt-in to dynamic LDS above 64 KB (hipFuncSetAttribute applies to the current device)
+static int ce_set_attributes(int device) {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 0 || device >= 64 || done[device]) return RR_OK;
+    const int ldsB = (128 + 384) * CE_LDK * 2, ldsP = 8 * 64 * (96 + 8) * 2;
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512)));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CE_FFN_BUF * 2));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * CE_HD * 4));
+    done[device] = true;
+    return RR_OK;
+}
+
+static int ce_reserve_f32(rr_ce* ce, int64_t tokens) {
+    if (tokens <= ce->cap32) return RR_OK;
+    RR_HIP_TRY(hipDeviceSynchronize());
+    hipFree(ce->qkv32); hipFree(ce->y32); hipFree(ce->inter32);
+    ce->qkv32 = ce->y32 = ce->inter32 = nullptr;
+    ce->cap32 = 0;
+    const size_t n = (size_t)rr_round_up(tokens, 4096);
+    hipError_t e = hipMalloc((void**)&ce->qkv32, n * 3 * CE_H * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->y32, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->inter32, n * CE_FFN * 4);
+    if (e != hipSuccess) { rr_set_error("rr_ce_forward: fp32 activation scratch for %lld tokens: %s", (long long)tokens, hipGetErrorString(e)); return RR_E_NOMEM; }
+    ce->cap32 = (int64_t)n;
+    return RR_OK;
+}
+
+// the forward pass of RR_CE_PRECISION_F32 (every operand fp32): embeddings -> per layer QKV, attention, output projection
+// + residual + LayerNorm, FFN (exact GELU) + residual + LayerNorm -> head
+static int ce_forward_f32(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_type_ids, const int32_t* d_pos_ids,
+                          const int32_t* d_cu_seqlens, int n_seqs, int T, int max_len, int mode, float* d_out, hipStream_t st) {
+    int rc = ce_reserve_f32(ce, T);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ce_embed_ln, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, d_token_ids, d_type_ids, d_pos_ids, T,
+                       ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type, ce->eln_g, ce->eln_b,
+                       ce->cfg.ln_eps, ce->h32, ce->hb);
+    const unsigned mt = (unsigned)((T + 127) / 128), ln_blocks = (unsigned)((T + 3) / 4);
+    const size_t att_lds = (size_t)2 * max_len * CE_HD * 4;
+    for (int l = 0; l < ce->cfg.n_layers; ++l) {
+        const rr_ce_layer& L = ce->layers[l];
+        hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(3 * CE_H / 128, mt), dim3(256), 0, st, ce->h32, L.wqkv32, L.bqkv, T, 3 * CE_H, CE_H, ce->qkv32);
+        hipLaunchKernelGGL(ce_attention_f32, dim3((unsigned)n_seqs, CE_HEADS), dim3(256), att_lds, st, ce->qkv32, d_cu_seqlens, ce->y32,
+                           0.17677669529663687f /* 1 / sqrt(32) */);
+        // (y32 holds the context; the projection's output goes to the first T x 384 floats of inter32)
+        hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->y32, L.wo32, L.bo, T, CE_H, CE_H, ce->inter32);
+        hipLaunchKernelGGL(ce_add_ln_f32, dim3(ln_blocks), dim3(256), 0, st, ce->inter32, ce->h32, T, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
+        hipLaunchKernelGGL((ce_gemm_f32<true>), dim3(CE_FFN / 128, mt), dim3(256), 0, st, ce->h32, L.w1_32, L.b1, T, CE_FFN, CE_H, ce->inter32);
+        hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->inter32, L.w2_32, L.b2, T, CE_H, CE_FFN, ce->y32);
+        hipLaunchKernelGGL(ce_add_ln_f32, dim3(ln_blocks), dim3(256), 0, st, ce->y32, ce->h32, T, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
+    }
+    if (mode == RR_CE_OUT_HIDDEN)
+        RR_HIP_TRY(hipMemcpyAsync(d_out, ce->h32, sizeof(float) * (size_t)T * CE_H, hipMemcpyDeviceToDevice, st));
+    else
+        hipLaunchKernelGGL(ce_head, dim3((unsigned)n_seqs), dim3(256), 0, st, ce->h32, d_cu_seqlens, ce->wp, ce->bp, ce->wc, ce->bc,
+                           ce->cfg.n_labels, mode, d_out);
+    return RR_OK;
+}
+
 extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_type_ids,
                                  const int32_t* d_pos_ids, const int32_t* d_cu_seqlens, int32_t n_seqs,
                                  int64_t n_tokens, int32_t max_len, int32_t mode, float* d_out, void* stream) {
@@ -948,16 +1176,16 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int T = (int)n_tokens;
-    static bool attr_set = false;
-    if (!attr_set) {
-        // dynamic LDS above 64 KB must be opted into per kernel
-        const int ldsB = (128 + 384) * CE_LDK * 2, ldsP = 8 * 64 * (96 + 8) * 2;
-        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP);
-        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP);
-        hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB);
-        hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512));
-        hipFuncSetAttribute((const void*)ce_ffn_fused<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CE_FFN_BUF * 2);
-        attr_set = true;
+    rc = ce_set_attributes(ce->device);
+    if (rc) return rc;
+    if (ce->cfg.precision == RR_CE_PRECISION_F32) {
+        hipEventRecord(ce->ev0, st);
+        rc = ce_forward_f32(ce, d_token_ids, d_type_ids, d_pos_ids, d_cu_seqlens, n_seqs, T, max_len, mode, d_out, st);
+        if (rc) return rc;
+        hipEventRecord(ce->ev1, st);
+        ce->timed = true;
+        RR_HIP_TRY(hipGetLastError());
+        return RR_OK;
     }
     const int smax_pad = (max_len + 31) & ~31;
     hipEventRecord(ce->ev0, st);

@@ -99,3 +99,6 @@ int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t
 void rr_flt_drop_pending(rr_index* ix);
 // fp32 rows (device, n x dim) -> the index's bf16 matrix rows [first, first + n), optional l2 normalise
 int rr_store_rows_bf16(rr_index* ix, int64_t first_row, int64_t n, float* d_rows_f32, float eps, hipStream_t st);
+
+// rr_api.hip: the address a kernel may use for p (device memory, or pinned host memory through its mapping)
+int rr_device_visible(const void* p, const void** out, const char* what);

@@ -861,9 +861,8 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
                         if (!(mx >= openf)) continue;                          // the whole 32-row tile is below the threshold
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const uint32_t code = (w >> (16 + 4 * g)) & 15u;       // 0..12 steps, then >= 16 | 24 | 40
-                            const float steps = code <= 12u ? (float)code : code == 13u ? 16.f : code == 14u ? 24.f : 40.f;
-                            const float bound = mx - steps * step;
+                            const uint32_t code = (w >> (16 + 4 * g)) & 15u;       // rr_flt_gap_code: 0..7 steps, then 8, 10 .. 22
+                            const float bound = mx - rr_flt_gap_steps(code) * step;
                             if (bound >= openf) {
                                 const uint32_t slot = atomicAdd(&counters[1], 1u);
                                 if (slot < RR_X3_MCAP) out_mtiles[(int64_t)q * RR_X3_MCAP + slot] = (uint32_t)(tt[u] * 8 + 4 * half + g);
@@ -1348,7 +1347,11 @@ extern "C" int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n
         (n_queries > RR_FLT_MAXQ && n_queries <= RR_FLT_MAXQ + RR_MFMA_MAXQ))       // (129 .. 192 go as two chunks)
         return RR_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = rr_scratch_enter(ix, st);
+    const void* q_vis = nullptr;
+    int rc = rr_device_visible(d_queries, &q_vis, "rr_dense_scan_dev (queries)");
+    if (rc) return rc;
+    d_queries = static_cast<const float*>(q_vis);
+    rc = rr_scratch_enter(ix, st);
     if (rc) return rc;
     rc = rr_ensure_scratch(ix, RR_MFMA_MAXQ);
     if (rc) return rc;
@@ -1395,7 +1398,12 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
     rr_flt_drop_pending(ix);
-    int rc = rr_scratch_enter(ix, st);
+    // (the queries may sit in pinned host memory: rr_pad_queries then reads them over PCIe, once -- no copy command)
+    const void* q_vis = nullptr;
+    int rc = rr_device_visible(d_queries, &q_vis, "rr_dense_topk_dev (queries)");
+    if (rc) return rc;
+    d_queries = static_cast<const float*>(q_vis);
+    rc = rr_scratch_enter(ix, st);
     if (rc) return rc;
     const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);   // kernels read whole query tiles
     const int64_t total = (int64_t)slots * ix->dim_pad;

@@ -116,9 +116,8 @@ __global__ __launch_bounds__(256) void rr_row_norm_max(const void* __restrict__ 
 }
 
 // ------------------------------------------------------------------ the filter scan
-// v_max_f32 / v_max3_f32 / v_cvt_u32_f32 spelled out: fmaxf() brings a canonicalising v_max x, x, x per operand with it
-// (three instructions per maximum); like fmaxf they return the other operand for a NaN.  The conversion saturates and
-// turns NaN into 0 (a C++ cast is undefined there).
+// v_max_f32 / v_max3_f32 spelled out: fmaxf() brings a canonicalising v_max x, x, x per operand with it
+// (three instructions per maximum); like fmaxf they return the other operand for a NaN.
 __device__ __forceinline__ float rr_vmax(float a, float b) {
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -127,11 +126,6 @@ __device__ __forceinline__ float rr_vmax(float a, float b) {
 __device__ __forceinline__ float rr_vmax3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ uint32_t rr_cvt_u32_sat(float x) {
-    uint32_t r;
-    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
 // rr_scan_flt below is the scan of FP32 rows (an fp32 index without its bf16 filter plane: RR_NO_SHADOW=1, or no room
@@ -351,8 +345,8 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
                 m8[g] = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
             }
             // 4 bytes per (32-row tile, query): the tile maximum as bf16 ROUNDED UP + for each 8-row M-tile how far
-            // below it its own maximum sits, in units of `step`, ROUNDED DOWN to a 4-bit code (0..12 steps, then
-            // >= 16, 24, 40).  The filter only asks "can this M-tile hold a score >= threshold": the decoded value
+            // below it its own maximum sits, in units of `step`, ROUNDED DOWN to a 4-bit code (rr_flt_gap_code, rr_x3.h).
+            // The filter only asks "can this M-tile hold a score >= threshold": the decoded value
             // max_up - steps(code) * step is an upper bound of the M-tile's maximum.
             const float m32 = fmaxf(fmaxf(m8[0], m8[1]), fmaxf(m8[2], m8[3]));
             gm[t] = fmaxf(gm[t], m32);
@@ -361,13 +355,7 @@ __global__ __launch_bounds__(RR_FLT_THREADS(NQ2), (RR_FLT_THREADS(NQ2) == 256 ? 
             uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);           // toward +inf; +-inf stay
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float gap = (m32 - m8[g]) * inv_step;                          // >= 0, in steps; inf - inf = NaN -> code 0
-                uint32_t code = (uint32_t)fminf(gap, 12.f);                          // 0 .. 12 steps exactly (rounded down), then
-                code = gap >= 16.f ? 13u : code;                                     // "at least 16 | 24 | 40 steps" (RR_FLT_GAP_STEPS):
-                code = gap >= 24.f ? 14u : code;                                     // an ordinary M-tile next to a top row sits ~30 eps
-                code = gap >= 40.f ? 15u : code;                                     // below it and must not be opened with it
-                code = gap == gap ? code : 0u;
-                word |= code << (16 + 4 * g);
+                word |= rr_flt_gap_code(m32, m8[g], inv_step) << (16 + 4 * g);
             }
             pend[t] = word;
         }
@@ -625,12 +613,7 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
             // the word: see rr_scan_flt (bf16 tile maximum rounded up + four 4-bit gap codes rounded down)
             const uint32_t b = __float_as_uint(m32);
             uint32_t word = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);
-            const float gu = (m32 - u) * inv_step, gw = (m32 - w) * inv_step;
-            uint32_t cu = rr_cvt_u32_sat(gu), cw = rr_cvt_u32_sat(gw);
-            cu = cu < 12u ? cu : 12u;
-            cw = cw < 12u ? cw : 12u;
-            cu += (gu >= 16.f ? 1u : 0u) + (gu >= 24.f ? 1u : 0u) + (gu >= 40.f ? 1u : 0u);
-            cw += (gw >= 16.f ? 1u : 0u) + (gw >= 24.f ? 1u : 0u) + (gw >= 40.f ? 1u : 0u);
+            const uint32_t cu = rr_flt_gap_code(m32, u, inv_step), cw = rr_flt_gap_code(m32, w, inv_step);
             const uint32_t mine = (cu | (cw << 8)) << code_shift;
             const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
             word |= rc[0] | rc[1];
@@ -693,37 +676,39 @@ __global__ __launch_bounds__(512, 2) void rr_scan_flt16(
 // loads is serial with the MFMAs of the SIMD (~60 cycles each beside 3 072 cycles of MFMA: DESIGN.md section 8).  Here
 // the roles are swapped for the 256-query launch:
 //   * one workgroup per CU, FOUR waves (one per SIMD, 512 registers each); wave w owns queries 64 w .. 64 w + 63 of the
-//     launch's 256 (waves 0, 1 = set 0; 2, 3 = set 1) and keeps their B fragments -- 4 fragments x 12 K-steps x 4
-//     registers = 192 -- in ACCUMULATION registers for the whole launch: no LDS planes at all;
-//   * the ROWS come through LDS, once per CU: a 32-row M-tile = 24 LDS-DMA pieces (global_load_lds_dwordx4) of 8 rows x
-//     128 B -- whole lines, half the address-path cost of fragment-shaped loads --, six per wave, three M-tiles ahead in
-//     a ring of four 24 KB buffers; all four waves read their A operands from that one image (ds_read_b128, one per 4
-//     MFMAs, conflict-free: a piece is stored 16-byte-swizzled by (row & 7) through its SOURCE addresses);
-//   * so the stream leaves HBM once for 256 queries without any pairing of workgroups, and a row costs a quarter of the
-//     vector-memory issue per query it did.
-// Per M-tile and wave: 96 MFMAs (16x16x32), 24 ds_read_b128, 6 LDS-DMA pieces, one raw s_barrier, the epilogue of its
-// 64 queries (two 32-query blocks, as in rr_scan_flt16) and two tile-word stores.  Runs: one per workgroup (G.n_waves =
-// number of runs), groups = 1/32 of a run.
-// NW = waves per workgroup: 4 (one per SIMD, 64 queries each) or 8 (two per SIMD, 32 queries each)
+//     launch's 256 (waves 0, 1 = set 0; 2, 3 = set 1) and keeps their B fragments -- 4 fragments of 16 queries x 12
+//     K-steps of 32 dims x 4 registers = 192 -- in ACCUMULATION registers for the whole launch: no LDS planes at all;
+//   * the ROWS come through LDS, once per CU: a 32-row M-tile = 24 LDS-DMA pieces of 8 rows x 128 B -- whole lines --,
+//     six per wave, three M-tiles ahead in a ring of four 24 KB images; all four waves read their A operands from that one
+//     image (ds_read_b128 = 16 rows x 32 dims, one per four MFMAs, conflict-free: a piece is stored 16-byte-swizzled
+//     through its SOURCE addresses);
+//   * so the stream leaves HBM once for 256 queries without any pairing of workgroups.
+// MFMA shape (round 3): v_mfma_f32_16x16x32_bf16.  The kernel is not paced by its cycles but by the clock the chip holds
+// under this load (1.2 - 1.5 GHz in-kernel, profiles/r03_fltq_asm_ablations_10M.txt): the same MACs as 16x16x32 MFMAs run
+// at a ~12 % higher clock than as 32x32x16 (same cycles per FLOP; MI355X_MICROARCH.md "DVFS give-back" (7)).
+// Per M-tile and wave: 96 MFMAs, 24 ds_read_b128, 6 LDS-DMA pieces, one raw s_barrier, the epilogue of its 64 queries
+// (two blocks of 32, as in rr_scan_flt16) and two tile-word stores.  Runs: one per workgroup (G.n_waves = number of
+// runs), groups = 1/32 of a run.
 // ASM: the steady-state M-tiles run through the hand-scheduled loop of rr_fltq_loop.inc (gen_fltq_loop.py): the same
 // MFMAs in the same order and the epilogue arithmetic of `piece()` bit for bit, so tile words and group maxima are those
 // of the C++ bodies -- which stay for the first five M-tiles of a run, the last few and the matrix's short last M-tile
-// (RR_FLTQ_NOASM=1 runs them everywhere: A/B and the ablation harness).
-template <int DBG = 0, int NW = 4, bool ASM = false>
-__global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
+// (RR_FLTQ_NOASM=1 runs them everywhere: A/B).
+// ABL (debug harness only): timing ablation of the hand-scheduled loop (gen_fltq_loop.py --abl), wrong results
+template <bool ASM = false, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void rr_scan_fltq(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ plane,   // [256][48] units: set 0, then set 1
     float* __restrict__ gmax, uint32_t* __restrict__ smax, const float* __restrict__ eps, int nq_a, int nq_b,
-    int64_t gmax_set_stride, unsigned long long* __restrict__ stamps = nullptr) {      // stamps: DBG & 128, [run][wave][4]
+    int64_t gmax_set_stride, unsigned long long* __restrict__ stamps = nullptr) {      // stamps (ABL != 0): [run][wave][4]
     constexpr int NB = 4;                             // ring of M-tile images
-    constexpr int F = 8 / NW;                         // 32-query fragments per wave
-    constexpr int PW = 24 / NW;                       // LDS-DMA pieces per wave and M-tile
+    constexpr int F = 2;                              // 32-query blocks (pairs of 16-query fragments) per wave
+    constexpr int PW = 6;                             // LDS-DMA pieces per wave and M-tile
     constexpr int TILE_UNITS = 32 * RR_X3_UNITS;      // 16-byte units per image (24 KB)
     __shared__ u32x4 ring[NB * TILE_UNITS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int run = blockIdx.x;
     if (run >= G.n_waves) return;                     // (whole workgroup)
-    const int set = w / (NW / 2);
-    const int qoff = 32 * F * (w % (NW / 2));         // this wave's first query inside its set
+    const int set = w >> 1;
+    const int qoff = 64 * (w & 1);                    // this wave's first query inside its set
     const int nq = set ? nq_b : nq_a;
     float* const gm_out = gmax + set * gmax_set_stride;
     uint32_t* const sm_out = smax + (size_t)set * RR_FLT_MAXQ * RR_MAX_SCAN_WAVES;
@@ -732,52 +717,54 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
     const int64_t t1 = t0 + G.tiles_per_wave < G.n_tiles ? t0 + G.tiles_per_wave : G.n_tiles;
     const int64_t m0 = t0 * 2, m1 = t1 * 2;           // 32-row M-tiles of this run
 
-    // ---- B fragments (v_mfma_f32_32x32x16_bf16: 32 queries x 16 dims): query 32 f + (l & 31) of this wave, dims 16 ks +
-    // 8 (l >> 5) .. + 7  ->  bq[ks][f], accumulation registers (2 x 24 x 4 = 192)
-    u32x4 bq[24][F];
+    // ---- B fragments (v_mfma_f32_16x16x32_bf16: 16 queries x 32 dims): query 16 n + (l & 15) of this wave, dims 32 ks +
+    // 8 (l >> 4) .. + 7  ->  bq[ks][n], accumulation registers (12 x 4 x 4 = 192)
+    u32x4 bq[12][4];
     {
-        const u32x4* src = plane + ((size_t)(32 * F * w + (lane & 31)) * RR_X3_UNITS + (lane >> 5));
+        const u32x4* src = plane + ((size_t)(64 * w + (lane & 15)) * RR_X3_UNITS + (lane >> 4));
 #pragma unroll
-        for (int ks = 0; ks < 24; ++ks)
+        for (int ks = 0; ks < 12; ++ks)
 #pragma unroll
-            for (int f = 0; f < F; ++f)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[ks][f]) : "v"(src + (32 * f) * RR_X3_UNITS + 2 * ks) : "memory");
+            for (int n = 0; n < 4; ++n)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(bq[ks][n]) : "v"(src + (16 * n) * RR_X3_UNITS + 4 * ks) : "memory");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int ks = 0; ks < 24; ++ks)
+        for (int ks = 0; ks < 12; ++ks)
 #pragma unroll
-            for (int f = 0; f < F; ++f) asm volatile("" : "+a"(bq[ks][f]));
+            for (int n = 0; n < 4; ++n) asm volatile("" : "+a"(bq[ks][n]));
     }
 
-    // ---- LDS-DMA: wave w brings rows 8 w .. 8 w + 7 of an M-tile, segment j = bytes 128 j .. 128 j + 127 of each row;
-    // lane l = (row r8 = l >> 3, slot l & 7) fetches piece (slot ^ r8 ^ (w >> 1)) so that the linear image holds piece p of
-    // row r8 of row group w in slot p ^ r8 ^ (w >> 1): the A reads below (32 rows x one 16-byte piece per half wave) then
-    // touch every bank group once per 16-lane access group
+    // ---- LDS-DMA: wave w brings rows 8 w .. 8 w + 7 of an M-tile (row group w), piece j = bytes 128 j .. 128 j + 127 of
+    // each row; lane l = (row r8 = l >> 3, slot l & 7) fetches the 16 bytes (slot ^ f) of its row's segment, f = (r8 >> 1)
+    // | (w & 1) << 2, so that the linear image holds 16-byte piece p of row r8 of row group w in slot p ^ f: the A reads
+    // below then touch every bank group once per ds_read_b128 lane group
     const int d_r8 = lane >> 3, d_slot = lane & 7;
-    const int rg = w * 4 / NW, jbase = (w % (NW / 4)) * PW;      // this wave's row group (8 rows) and first line segment
-    auto dma_tile = [&](int64_t mt, int buf, int j0 = 0, int j1 = 24) {      // pieces j0 .. j1 - 1 of the wave's PW (default: all)
+    auto dma_tile = [&](int64_t mt, int buf, int j0 = 0, int j1 = PW) {      // pieces j0 .. j1 - 1 of the wave's six (default: all)
         mt = mt < m1 ? mt : m1 - 1;                   // (past the end: redundant, never read)
-        if (DBG & 64) mt = m0 + (mt & 1);             // timing only: cache hits
-        int64_t row = mt * 32 + 8 * rg + d_r8;
+        int64_t row = mt * 32 + 8 * w + d_r8;
         row = row < G.n_rows ? row : G.n_rows - 1;
-        const u32x4* src = mat + row * RR_X3_UNITS + (d_slot ^ d_r8 ^ (rg >> 1)) + 8 * jbase;
-        u32x4* dst = ring + buf * TILE_UNITS + (rg * 6 + jbase) * 64;
+        const u32x4* src = mat + row * RR_X3_UNITS + (d_slot ^ (d_r8 >> 1) ^ ((w & 1) << 2));
+        u32x4* dst = ring + buf * TILE_UNITS + (w * 6) * 64;
 #pragma unroll
         for (int j = 0; j < PW; ++j)
             if (j >= j0 && j < j1)
                 __builtin_amdgcn_global_load_lds(src + 8 * j, (__attribute__((address_space(3))) void*)(dst + j * 64), 16, 0, 0);
     };
-    // ---- A operand reads (32 rows x 16 dims): lane (row R = l & 31, k half l >> 5) of K-step ks wants piece P = 2 ks + (l >> 5):
-    //      unit = ((R >> 3) * 6 + (P >> 3)) * 64 + (R & 7) * 8 + ((P & 7) ^ (R & 7) ^ (R >> 4))
-    // (P & 7 = 2 (ks & 3) + k half: four per-lane addresses, one per ks & 3; P >> 3 = ks >> 2 goes into the offset field)
-    const int aR = lane & 31, aH = lane >> 5, ar8 = aR & 7;
-    const int a_base = ((aR >> 3) * 6) * 64 + ar8 * 8;
+    // ---- A operand reads (16 rows x 32 dims): lane (row R = 16 r + (l & 15), k quarter l >> 4) of K-step ks wants piece
+    // P = 4 ks + (l >> 4) of its row:  unit = ((R >> 3) * 6 + (P >> 3)) * 64 + (R & 7) * 8 + ((P & 7) ^ f(R & 7, R >> 3))
+    // (P & 7 = 4 (ks & 1) + k quarter: two per-lane addresses, by the parity of ks; P >> 3 = ks >> 1, the row half r and
+    // the image go into the offset field.)  A ds_read_b128 is served in four groups of 16 lanes, each holding the 16 rows
+    // of the half once with two k quarters that differ in bit 0 (MI355X_MICROARCH.md, LDS): for the eight rows of equal
+    // parity, (r8 >> 1) | (row group & 1) << 2 XOR that bit is a bijection onto the eight slots -- conflict-free.
+    const int aR = lane & 15, aQ = lane >> 4, ar8 = aR & 7;
     const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring;
-    uint32_t a_addr[4];
+    uint32_t a_addr[2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) a_addr[m] = ring_lds + 16u * (uint32_t)(a_base + ((2 * m + aH) ^ ar8 ^ (aR >> 4)));
-#define RR_FLTQ_READ_A(dst, tile_off, ks) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a_addr[(ks) & 3] + (tile_off)), "n"(16 * (((ks) >> 2) * 64)) : "memory")
+    for (int m = 0; m < 2; ++m)
+        a_addr[m] = ring_lds + 16u * (uint32_t)(((aR >> 3) * 6) * 64 + ar8 * 8 + ((4 * m + aQ) ^ (ar8 >> 1) ^ ((aR >> 3) << 2)));
+#define RR_FLTQ_READ_A(dst, tile_off, u) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a_addr[((u) >> 1) & 1] + (tile_off)), \
+                 "n"(((u) & 1) * (16 * RR_X3_UNITS * 16) + 1024 * ((u) >> 2)) : "memory")
     const int c = lane & 31, h = lane >> 5;
     const uint32_t code_shift = 16u + 4u * (uint32_t)h;
     const float step = rr_flt_gap_step(eps_set, nq);
@@ -785,22 +772,23 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
     float gm[F];
 #pragma unroll
     for (int t = 0; t < F; ++t) gm[t] = -INFINITY;
-    f32x16 acc[2][F];                                 // [set P = M-tile parity][fragment of 32 queries]
+    // accumulators: [set P = M-tile parity][32-query block t]: sixteen registers = (row half r, fragment 2 t + nn) at
+    // 8 r + 4 nn .. + 3.  C layout of one MFMA (lane l, register i): row 16 r + 4 (l >> 4) + i, query 16 n + (l & 15).
+    f32x16 acc[2][F];
 
-    // ---- the epilogue of one M-tile for this wave's 64 queries: block t = fragment t = queries 32 t .. 32 t + 31.
-    // C layout (lane (query c = l & 31, h = l >> 5), register 4 g + i): row 8 g + 4 h + i.  Pieces of at most three
-    // vector instructions, one behind every MFMA of the NEXT M-tile (a 32-cycle MFMA leaves the vector issue 24 cycles;
-    // with one wave per SIMD only what stands right behind an MFMA in program order issues in its shadow), on the
-    // accumulator set that M-tile does not write.  24 pieces per block: MFMA 2 ks + f of the next M-tile runs piece
-    // (t = its index / 24, k = its index % 24).  `live` = there is a previous M-tile (first body: zeros, effects off).
+    // ---- the epilogue of one M-tile for this wave's 64 queries, block t = queries 32 t .. 32 t + 31, in pieces of at most
+    // four vector instructions: placed behind the MFMAs of the NEXT M-tile (C++ bodies) / spread over its MFMA shadows
+    // (generated loop), on the accumulator set that M-tile does not write.  `live` = there is a previous M-tile.
     float ep8[F][4], eu[F], ew[F], em32[F], egu[F], egw[F], etmp0[F], etmp1[F];
     uint32_t ecu[F], ecw[F], eword[F];
     auto piece = [&](int P, int t, int k, int64_t tile, bool live) {      // (P, t, k: constants once unrolled)
-        if (k < 4) {                                   // lane-local maxima of the four 8-row M-tiles' rows in this k half
+        if (k < 4) {                                   // lane-local maxima: rows 4 (l >> 4) .. + 3 of (row half k >> 1, fragment 2 t + (k & 1))
             ep8[t][k] = rr_vmax3(acc[P][t][4 * k], acc[P][t][4 * k + 1], rr_vmax(acc[P][t][4 * k + 2], acc[P][t][4 * k + 3]));
-        } else if (k == 4 || k == 5) {                 // pair M-tiles (0, 1) / (2, 3): v_permlane32_swap(x, y) = {x.lo, y.lo}, {x.hi, y.hi}
+        } else if (k == 4 || k == 5) {
+            // v_permlane16_swap(x, y) = {x.row0, y.row0, x.row2, y.row2}, {x.row1, y.row1, x.row3, y.row3} (rows of 16 lanes): the
+            // maximum of the two holds, for query 32 t + (l & 31), the 8-row M-tile 2 r in lanes < 32 and 2 r + 1 above
             const int g = k == 4 ? 0 : 2;
-            const auto rs = __builtin_amdgcn_permlane32_swap(__float_as_uint(ep8[t][g]), __float_as_uint(ep8[t][g + 1]), false, false);
+            const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(ep8[t][g]), __float_as_uint(ep8[t][g + 1]), false, false);
             const float v = rr_vmax(__uint_as_float(rs[0]), __uint_as_float(rs[1]));
             if (k == 4) eu[t] = v;                     // lanes < 32: M-tile 0, lanes >= 32: M-tile 1
             else ew[t] = v;                            // M-tiles 2 / 3
@@ -815,28 +803,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
         } else if (k == 8) {
             const uint32_t b = __float_as_uint(em32[t]);
             eword[t] = (b >> 31) ? (b >> 16) : ((b + 0xFFFFu) >> 16);
-        } else if (k == 9) {
-            egu[t] = (em32[t] - eu[t]) * inv_step;
+        } else if (k == 9) {                           // the two gap codes of this lane (rr_flt_gap_code, spelled out in four pieces)
+            egu[t] = __builtin_fmaf(em32[t] - eu[t], inv_step, 8.0f);
         } else if (k == 10) {
-            egw[t] = (em32[t] - ew[t]) * inv_step;
+            egw[t] = __builtin_fmaf(em32[t] - ew[t], inv_step, 8.0f);
         } else if (k == 11) {
-            const uint32_t cu = rr_cvt_u32_sat(egu[t]);
-            ecu[t] = cu < 12u ? cu : 12u;
+            asm("v_min_f32 %0, 0x41ffeb85, %0" : "+v"(egu[t]));
+            ecu[t] = (__float_as_uint(egu[t]) >> 20) & 15u;
         } else if (k == 12) {
-            const uint32_t cw = rr_cvt_u32_sat(egw[t]);
-            ecw[t] = cw < 12u ? cw : 12u;
-        } else if (k >= 13 && k <= 15) {               // one threshold of the coarse codes per piece
-            ecu[t] += egu[t] >= (k == 13 ? 16.f : k == 14 ? 24.f : 40.f) ? 1u : 0u;
-        } else if (k >= 16 && k <= 18) {
-            ecw[t] += egw[t] >= (k == 16 ? 16.f : k == 17 ? 24.f : 40.f) ? 1u : 0u;
-        } else if (k == 19) {
+            asm("v_min_f32 %0, 0x41ffeb85, %0" : "+v"(egw[t]));
+            ecw[t] = (__float_as_uint(egw[t]) >> 20) & 15u;
+        } else if (k == 13) {
             const uint32_t mine = (ecu[t] | (ecw[t] << 8)) << code_shift;
             const auto rc = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
             ecu[t] = rc[0];
             ecw[t] = rc[1];
-        } else if (k == 20) {
+        } else if (k == 14) {
             eword[t] |= ecu[t] | ecw[t];
-        } else if (k == 21) {
+        } else if (k == 15) {
             if (h == 0 && live) reinterpret_cast<uint32_t*>(gm_out)[tile * RR_FLT_MAXQ + qoff + 32 * t + c] = eword[t];   // ONE store
         }
     };
@@ -852,113 +836,86 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
         }
     };
     auto canon_set = [&](int P, int64_t tile) {       // rows past the end (and NaNs) of the matrix's last, short M-tile -> -inf
-        const int64_t rbase = tile * 32 + 4 * h;
+        const int64_t rbase = tile * 32 + 4 * (lane >> 4);
 #pragma unroll
-        for (int f = 0; f < F; ++f)
+        for (int t = 0; t < F; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v = {acc[P][f][4 * g], acc[P][f][4 * g + 1], acc[P][f][4 * g + 2], acc[P][f][4 * g + 3]};
-                v = rr_x3_canon(v, rbase + 8 * g, G.n_rows);
-                acc[P][f][4 * g] = v.x; acc[P][f][4 * g + 1] = v.y; acc[P][f][4 * g + 2] = v.z; acc[P][f][4 * g + 3] = v.w;
+            for (int k = 0; k < 4; ++k) {             // registers 4 k ..: row half k >> 1
+                f32x4 v = {acc[P][t][4 * k], acc[P][t][4 * k + 1], acc[P][t][4 * k + 2], acc[P][t][4 * k + 3]};
+                v = rr_x3_canon(v, rbase + 16 * (k >> 1), G.n_rows);
+                acc[P][t][4 * k] = v.x; acc[P][t][4 * k + 1] = v.y; acc[P][t][4 * k + 2] = v.z; acc[P][t][4 * k + 3] = v.w;
             }
     };
 
 #pragma unroll
-    for (int f = 0; f < F; ++f)
+    for (int t = 0; t < F; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[1][f][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[1][t][e] = 0.f;
     dma_tile(m0, 0);
     dma_tile(m0 + 1, 1);
     dma_tile(m0 + 2, 2);
-    uint64_t dbg_wait = 0, dbg_mfma = 0, dbg_epi = 0;
-    const uint64_t dbg_t0 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
-    constexpr int AD = 4;                             // A operands requested this many K-steps (2 MFMAs each) ahead
+    const uint64_t dbg_t0 = ABL != 0 ? __builtin_amdgcn_s_memtime() : 0;
+    constexpr int AD = 4;                             // A operands requested this many operands (4 MFMAs each) ahead
     bf16x8 a[AD + 1];
-    f32x4 acc16[2][F][2];                             // (DBG & 256 only)
-    if (DBG & 256) {
-#pragma unroll
-        for (int i = 0; i < 4 * F; ++i) acc16[i / (2 * F)][(i / 2) % F][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     auto body = [&](auto PC, int64_t mt) {
         constexpr int P = decltype(PC)::value;        // accumulator set of THIS M-tile; 1 - P: the previous one's
         const int it = (int)(mt - m0), buf = it & (NB - 1);
         const bool have_prev = it > 0;
-        const uint64_t ts0 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
         // this wave's six pieces of M-tile mt have landed once at most the two younger M-tiles' pieces (12) and the four
         // word stores issued with them are outstanding; then all four waves' pieces have, behind the barrier -- which also
         // says that every wave is done reading M-tile mt - 1
-        // (per M-tile and wave: PW pieces and F word stores)
-        if (!(DBG & 4)) {
-            if (it < 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PW + F)) : "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        const uint64_t ts1 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
+        if (it < 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (PW + F)) : "memory");
+        __builtin_amdgcn_s_barrier();
         if (have_prev && (mt - 1) * 32 + 32 > G.n_rows) canon_set(1 - P, mt - 1);
         const uint32_t toff = (uint32_t)buf * (TILE_UNITS * 16);
-        if ((DBG & 8) && it == 0) {                   // (ablation: no A reads in the loop -- five once, then stale registers)
+        f32x4 c4[2][4];                               // [row half][fragment] of this M-tile
 #pragma unroll
-            for (int i = 0; i <= AD; ++i) RR_FLTQ_READ_A(a[i], toff, i);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+        for (int i = 0; i < AD; ++i) RR_FLTQ_READ_A(a[i], toff, i);
 #pragma unroll
-        for (int i = 0; i < AD; ++i)
-            if (!(DBG & 8)) RR_FLTQ_READ_A(a[i], toff, i);
+        for (int u = 0; u < 24; ++u) {                // operand u = 2 ks + r: rows 16 r .. + 15, dims 32 ks .. + 31; four MFMAs
+            if (u + AD < 24) RR_FLTQ_READ_A(a[(u + AD) % (AD + 1)], toff, u + AD);
+            // reads return in order: with the (up to AD) younger ones outstanding, this operand's is in
+            if (u + AD < 24) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(AD) : "memory");
+            else if (23 - u == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            else if (23 - u == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            else if (23 - u == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(a[u % (AD + 1)]));
 #pragma unroll
-        for (int ks = 0; ks < 24; ++ks) {             // 16-dim K-steps: one A operand, two MFMAs (the wave's two query fragments)
-            if (!(DBG & 8)) {
-                if (ks + AD < 24) RR_FLTQ_READ_A(a[(ks + AD) % (AD + 1)], toff, ks + AD);
-                // reads return in order: with the (up to AD) younger ones outstanding, this K-step's is in
-                if (ks + AD < 24) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(AD) : "memory");
-                else if (23 - ks == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-                else if (23 - ks == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                else if (23 - ks == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            asm volatile("" : "+v"(a[ks % (AD + 1)]));
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                constexpr int PB = 24;                  // pieces (= MFMAs) per 32-query block
-                const int idx = F * ks + f;             // MFMA of this M-tile: 0 .. 24 F - 1
-                if (DBG & 256) {                        // (ablation, wrong results: the same MACs as two 16x16x32 MFMAs, 16 cycles each)
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[P][f][0]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc16[P][f][1]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
-                }
-                else if (ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
-                else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[P][f]) : "v"(a[ks % (AD + 1)]), "a"(bq[ks][f]));
+            for (int n = 0; n < 4; ++n) {
+                constexpr int PB = 48;                  // MFMAs per 32-query block of the PREVIOUS M-tile's epilogue (16 pieces used)
+                const int idx = 4 * u + n;              // MFMA of this M-tile: 0 .. 95
+                if (u < 2) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c4[u & 1][n]) : "v"(a[u % (AD + 1)]), "a"(bq[u >> 1][n]));
+                else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c4[u & 1][n]) : "v"(a[u % (AD + 1)]), "a"(bq[u >> 1][n]));
                 __builtin_amdgcn_sched_barrier(0);      // the piece stands BEHIND its MFMA (in front of it, it would only delay it)
-                if (!(DBG & 2) && (!(DBG & 512) || idx % PB < 8)) piece(1 - P, idx / PB, idx % PB, mt - 1, have_prev);
-                // the epilogue has no piece for the last two MFMAs of a block: the wave's LDS-DMA pieces of the M-tile three ahead
-                // go there (its buffer held M-tile mt - 1: read out, see the barrier), the rest behind the smallest pieces
-                if (DBG & 1) {                       // (ablation: no LDS-DMA in the loop; the A operands are stale LDS bytes)
-                } else if (NW == 4) {
-                    if (idx % PB >= 22) dma_tile(mt + 3, (it + 3) & (NB - 1), 2 * (idx / PB) + idx % PB - 22, 2 * (idx / PB) + idx % PB - 21);
-                    if (idx == 5) dma_tile(mt + 3, (it + 3) & (NB - 1), 4, 5);
-                    if (idx == 7) dma_tile(mt + 3, (it + 3) & (NB - 1), 5, 6);
-                } else {
-                    if (idx >= 22) dma_tile(mt + 3, (it + 3) & (NB - 1), idx - 22, idx - 21);
-                    if (idx == 5) dma_tile(mt + 3, (it + 3) & (NB - 1), 2, 3);
-                }
+                if (idx % PB < 16) piece(1 - P, idx / PB, idx % PB, mt - 1, have_prev);
+                // the wave's LDS-DMA pieces of the M-tile three ahead (its image held M-tile mt - 1: read out, see the barrier)
+                if (idx % PB >= 16 && idx % PB < 19) dma_tile(mt + 3, (it + 3) & (NB - 1), 3 * (idx / PB) + idx % PB - 16, 3 * (idx / PB) + idx % PB - 15);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        const uint64_t ts2 = (DBG & 128) ? __builtin_amdgcn_s_memtime() : 0;
-        if (have_prev && !(DBG & 2)) finish_tile(mt - 1);
-        if (DBG & 128) {
-            const uint64_t ts3 = __builtin_amdgcn_s_memtime();
-            dbg_wait += ts1 - ts0; dbg_mfma += ts2 - ts1; dbg_epi += ts3 - ts2;
-        }
+        // the last MFMAs' results are copied by vector instructions below: the wait states the compiler would count for its own
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c4[0][0]), "+v"(c4[0][1]), "+v"(c4[0][2]), "+v"(c4[0][3]), "+v"(c4[1][0]), "+v"(c4[1][1]),
+                     "+v"(c4[1][2]), "+v"(c4[1][3]) :: "memory");
+#pragma unroll
+        for (int t = 0; t < F; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[P][t][4 * k + i] = c4[k >> 1][2 * t + (k & 1)][i];
+        if (have_prev) finish_tile(mt - 1);
     };
-    if constexpr (ASM && NW == 4 && DBG == 0) {
+    if constexpr (ASM) {
         // ---- wave-uniform operands of the hand-scheduled loop (SGPRs: readfirstlane, the compiler sees tid >> 6 per lane)
         const int wu = __builtin_amdgcn_readfirstlane(w);
         const uint32_t lds_w = __builtin_amdgcn_readfirstlane(ring_lds) + (uint32_t)wu * (PW * 1024);
-        const uint32_t dma_voff = (uint32_t)d_r8 * 768u + 16u * (uint32_t)(d_slot ^ d_r8 ^ (wu >> 1));
+        const uint32_t dma_voff = (uint32_t)d_r8 * 768u + 16u * (uint32_t)(d_slot ^ (d_r8 >> 1) ^ ((wu & 1) << 2));
         const uint32_t st_voff = h == 0 ? (uint32_t)(qoff + c) * 4u : 0xFFFFF000u;      // (upper half: out of range, dropped)
         const uint32_t inv_step_s = __builtin_amdgcn_readfirstlane(__float_as_uint(inv_step));
-        uint32_t al[4], ah[4];
+        uint32_t al[2], ah[2];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 2; ++m) {
             al[m] = a_addr[m];
             ah[m] = a_addr[m] + 2u * (TILE_UNITS * 16);
         }
@@ -998,6 +955,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
                 //  know that MFMAs -- inline asm to it -- wrote them: the matrix pipe must have drained on both sides; the
                 //  loop ends with its own s_nops, in front of the copies out)
                 asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+#ifdef RR_DEBUG_HARNESS
+#include "rr_fltq_loop_abl.inc"
+                else
+#endif
 #include "rr_fltq_loop.inc"
                 it += 4 * n_it;
                 finish_tile(m0 + it - 2);                               // (flushes only where that M-tile closes a group)
@@ -1013,23 +974,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
         body(std::integral_constant<int, 1>{}, mt + 1);
     }
     }
-    if (DBG & 256) {
-#pragma unroll
-        for (int i = 0; i < 4 * F; ++i) asm volatile("" :: "v"(acc16[i / (2 * F)][(i / 2) % F][i & 1]));
-    }
     // tail: the last M-tile (set 1) has its epilogue to run
-    if constexpr (F == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
-    else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0]) :: "memory");
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[1][0]), "+v"(acc[1][1]) :: "memory");
     if ((m1 - 1) * 32 + 32 > G.n_rows) canon_set(1, m1 - 1);
 #pragma unroll
     for (int t = 0; t < F; ++t)
 #pragma unroll
-        for (int kk = 0; kk < 24; ++kk) piece(1, t, kk, m1 - 1, true);
+        for (int kk = 0; kk < 16; ++kk) piece(1, t, kk, m1 - 1, true);
     finish_tile(m1 - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring's last (redundant) pieces
-    if ((DBG & 128) && stamps && lane == 0) {
-        unsigned long long* o = stamps + ((size_t)run * NW + w) * 4;
-        o[0] = dbg_wait; o[1] = dbg_mfma; o[2] = dbg_epi; o[3] = __builtin_amdgcn_s_memtime() - dbg_t0;
+    if (ABL != 0 && stamps && lane == 0) {
+        unsigned long long* o = stamps + ((size_t)run * 4 + w) * 4;
+        o[0] = 0; o[1] = 0; o[2] = 0; o[3] = __builtin_amdgcn_s_memtime() - dbg_t0;
     }
     if (h == 0) {
         const int cg = (int)G.tiles_per_group;
@@ -1038,6 +994,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void rr_scan_fltq(
             for (int t = 0; t < F; ++t) sm_out[((int64_t)run * G.gpw + k) * RR_FLT_MAXQ + qoff + 32 * t + c] = 0u;
     }
 }
+#undef RR_FLTQ_READ_A
 
 // ------------------------------------------------------------------ store prefilter: sampled thresholds
 // Every `stride`-th 32-row tile of the bf16 matrix / plane is scored against the launch's query planes (the same bf16
@@ -1263,7 +1220,7 @@ static rr_scan_geom rr_flt_geom(rr_index* ix, bool dual = false) {
 // geometry of rr_scan_fltq: one run per resident workgroup (= CU), 32 selection groups per run
 static rr_scan_geom rr_fltq_geom(rr_index* ix) {
     static int runs = 0;
-    if (!runs) runs = rr_resident_waves((const void*)rr_scan_fltq<0>, 256, ix->device) / 4;
+    if (!runs) runs = rr_resident_waves((const void*)rr_scan_fltq<true>, 256, ix->device) / 4;
     rr_scan_geom G = rr_make_geom(ix, runs / 4);      // (rr_make_geom counts 4 "waves" per resident block)
     G.qs = RR_FLT_MAXQ;
     G.mm_pairs = 3;
@@ -1322,7 +1279,7 @@ static int64_t rr_flt_smax_set_stride() { return (int64_t)RR_FLT_MAXQ * RR_MAX_S
 template <int NQ2, bool SCAN_BF16>
 static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const void* scan_mat, const float* d_q, int nq,
                            int pool, rr_flt_bounds bounds, hipStream_t st, const float** sigma_out,
-                           bool launch_scan = true, bool allow_prefilter = true) {
+                           bool launch_scan = true, bool allow_prefilter = true, int prep_sets = 1) {   // prep_sets: planes + bounds of 0 | this | this and the next set (one launch)
     constexpr int THREADS = RR_FLT_THREADS(NQ2);
     constexpr int QN = 32 * NQ2;
     unsigned short* plane = reinterpret_cast<unsigned short*>(ix->d_qplanes) + (size_t)set * RR_FLT_MAXQ * 384;
@@ -1330,7 +1287,8 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
     float* eps = X.eps + set * RR_FLT_MAXQ;
     float* gmax = ix->d_gmax + set * rr_flt_mmax_set_stride(G);
     uint32_t* smax = ix->d_smax + set * rr_flt_smax_set_stride();
-    hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN), dim3(64), 0, st, d_q, plane, eps, bounds);   // (planes in memory order)
+    if (prep_sets)
+        hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN * prep_sets), dim3(64), 0, st, d_q, plane, eps, bounds);   // (planes in memory order)
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     // Store prefilter (bf16 stream, >= 2M rows): a 1/64 tile sample gives every query sigma = its m-th largest sampled
     // tile maximum - 2.05 eps.  The m-th largest of a 1/stride sample sits near rank m * stride of all rows; m leaves the
@@ -1469,28 +1427,27 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
     // the two samples cost 0.125 (r02, same box: 2.74 -> 2.67 ms per step without them), so it runs without.
     static const bool dual_prefilter = getenv("RR_DUAL_PREFILTER") != nullptr;
     const bool pre = !dual || dual_prefilter;
-    int rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 0, G, scan_mat, d_q, nq_a, pool, bounds, st, &sg0, !dual, pre);
+    // (nq_a = RR_FLT_MAXQ: the two sets' query slots, planes and bounds are contiguous -- one preparation launch for both
+    //  when nothing sits between them)
+    const bool prep_both = dual && !pre && nq_a == RR_FLT_MAXQ;
+    int rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 0, G, scan_mat, d_q, nq_a, pool, bounds, st, &sg0, !dual, pre, prep_both ? 2 : 1);
     if (rc != RR_OK) return rc;
-    rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 1, G, scan_mat, d_q + (int64_t)nq_a * ix->dim_pad, nq_b, pool, bounds, st, &sg1, !dual, pre);
+    rc = rr_flt_scan_set<4, SCAN_BF16>(ix, 1, G, scan_mat, d_q + (int64_t)nq_a * ix->dim_pad, nq_b, pool, bounds, st, &sg1, !dual, pre,
+                                       prep_both ? 0 : 1);
     if (rc != RR_OK) return rc;
     if (fltq) {
         const rr_x3_scratch X = rr_x3_scratch_of(ix);
         const int slot = rr_scan_events_begin(ix, st);
         rr_scan_note(ix, 5, 9, nq_a + nq_b, 1, 2);
-        static const bool w8 = getenv("RR_FLTQ_W8") != nullptr;
         static const bool noasm = getenv("RR_FLTQ_NOASM") != nullptr;    // the C++ bodies everywhere (A/B)
-        if (w8)
-            hipLaunchKernelGGL((rr_scan_fltq<0, 8>), dim3(G.n_waves), dim3(512), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+        if (noasm)
+            hipLaunchKernelGGL((rr_scan_fltq<false>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
                                reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
                                rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
-        else if (noasm)
-            hipLaunchKernelGGL((rr_scan_fltq<0>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
-                               reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
-                               rr_flt_mmax_set_stride(G));
         else
-            hipLaunchKernelGGL((rr_scan_fltq<0, 4, true>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
+            hipLaunchKernelGGL((rr_scan_fltq<true>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(scan_mat), G,
                                reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, X.eps, nq_a, nq_b,
-                               rr_flt_mmax_set_stride(G));
+                               rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
         rr_scan_events_end(ix, slot, st);
         RR_HIP_TRY(hipGetLastError());
     } else if (dual) {
@@ -1634,8 +1591,8 @@ static float rr_debug_time_flt(rr_index* ix, hipStream_t st, int reps) {
     return total / reps;
 }
 
-template <int DBG>
-static float rr_debug_time_fltq(rr_index* ix, hipStream_t st, int reps) {
+template <int ABL>
+static float rr_debug_time_fltq_asm(rr_index* ix, hipStream_t st, int reps) {
     if (!ix->shadow_valid) return -1.f;
     const rr_scan_geom G = rr_fltq_geom(ix);
     unsigned long long* d_st = nullptr;
@@ -1646,23 +1603,27 @@ static float rr_debug_time_fltq(rr_index* ix, hipStream_t st, int reps) {
     float total = 0.f;
     for (int r = 0; r < reps + 1; ++r) {
         hipEventRecord(e0, st);
-        hipLaunchKernelGGL((rr_scan_fltq<DBG>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
+        hipLaunchKernelGGL((rr_scan_fltq<true, ABL>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
                            reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128, 128,
-                           rr_flt_mmax_set_stride(G), d_st);
+                           rr_flt_mmax_set_stride(G), ABL ? d_st : (unsigned long long*)nullptr);
         hipEventRecord(e1, st);
         hipEventSynchronize(e1);
         float ms = 0.f;
         hipEventElapsedTime(&ms, e0, e1);
         if (r) total += ms;
     }
-    if (DBG & 128) {
+    if (ABL) {
         std::vector<unsigned long long> hst((size_t)16 * G.n_waves);
         hipMemcpy(hst.data(), d_st, hst.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        double sum[4] = {0, 0, 0, 0};
-        for (size_t k = 0; k < hst.size(); ++k) sum[k & 3] += (double)hst[k];
-        const double tiles = (double)((G.n_rows + 31) / 32) * 4;       // every wave of a workgroup walks every M-tile of its run
-        fprintf(stderr, "[fltq stamps %d] per M-tile and wave, shader cycles: wait + barrier %.0f, MFMA loop %.0f, epilogue + DMA issue %.0f; "
-                        "tile loop per wave %.0f\n", DBG & ~128, sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / (4.0 * G.n_waves));
+        double cyc = 0, cmax = 0;
+        for (size_t k = 3; k < (size_t)16 * G.n_waves; k += 4) {
+            cyc += (double)hst[k];
+            if ((double)hst[k] > cmax) cmax = (double)hst[k];
+        }
+        cyc /= 4.0 * G.n_waves;
+        const double mt = (double)((G.n_rows + 31) / 32) / G.n_waves;
+        fprintf(stderr, "[fltq asm loop, ablation %d] %.0f cycles per wave (slowest wave %.0f) = %.0f per M-tile; %.3f ms per launch => %.2f GHz\n",
+                ABL, cyc, cmax, cyc / mt, total / reps, cyc / (total / reps) * 1e-6);
     }
     hipFree(d_st); hipEventDestroy(e0); hipEventDestroy(e1);
     return total / reps;
@@ -1682,11 +1643,11 @@ extern "C" int rr_debug_fltq_compare(rr_index* ix, int64_t* out) {
         RR_HIP_TRY(hipMemsetAsync(ix->d_gmax, 0xA5, words * 4, st));
         RR_HIP_TRY(hipMemsetAsync(ix->d_smax, 0xA5, groups * 4, st));
         if (v == 0)
-            hipLaunchKernelGGL((rr_scan_fltq<0>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
+            hipLaunchKernelGGL((rr_scan_fltq<false>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
                                reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128, 128,
                                rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
         else
-            hipLaunchKernelGGL((rr_scan_fltq<0, 4, true>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
+            hipLaunchKernelGGL((rr_scan_fltq<true>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
                                reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128, 128,
                                rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
         RR_HIP_TRY(hipGetLastError());
@@ -1765,35 +1726,12 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
             *out_ms = rr_debug_time_flt<192, true>(ix, st, reps);
             break;
         // 400 (16x16x32 kernel only; wrong results): stamped, cached, without the B-fragment reads
-        // 2000 + bits: rr_scan_fltq with in-kernel stamps, 1000 + bits: without (a 256-query search must have run: planes of
-        // both sets, scratch).  bits: 1 no LDS-DMA in the loop, 2 no epilogue pieces / stores, 4 no vmcnt wait + barrier, 8 no A
-        // reads in the loop, 64 pieces from cache-resident rows, 256 16x16x32 MFMAs (same MACs), 512 epilogue: tile maxima only
-#define RR_FLTQ_CASE(b) case 2000 + (b): *out_ms = rr_debug_time_fltq<128 | (b)>(ix, st, reps); break; \
-                        case 1000 + (b): *out_ms = rr_debug_time_fltq<(b)>(ix, st, reps); break;
-        RR_FLTQ_CASE(0) RR_FLTQ_CASE(1) RR_FLTQ_CASE(2) RR_FLTQ_CASE(3) RR_FLTQ_CASE(7) RR_FLTQ_CASE(15) RR_FLTQ_CASE(64) RR_FLTQ_CASE(66)
-        RR_FLTQ_CASE(256 + 3) RR_FLTQ_CASE(256 + 7) RR_FLTQ_CASE(256 + 15) RR_FLTQ_CASE(512) RR_FLTQ_CASE(512 + 1)
-#undef RR_FLTQ_CASE
-        case 3000: {      // the hand-scheduled loop (the product's default 256-query kernel), timed like the variants above
-            RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
-            const rr_scan_geom G = rr_fltq_geom(ix);
-            hipEvent_t e0, e1;
-            hipEventCreate(&e0); hipEventCreate(&e1);
-            float total = 0.f;
-            for (int r = 0; r < reps + 1; ++r) {
-                hipEventRecord(e0, st);
-                hipLaunchKernelGGL((rr_scan_fltq<0, 4, true>), dim3(G.n_waves), dim3(256), 0, st, reinterpret_cast<const u32x4*>(ix->d_shadow), G,
-                                   reinterpret_cast<const u32x4*>(ix->d_qplanes), ix->d_gmax, ix->d_smax, rr_x3_scratch_of(ix).eps, 128, 128,
-                                   rr_flt_mmax_set_stride(G), (unsigned long long*)nullptr);
-                hipEventRecord(e1, st);
-                hipEventSynchronize(e1);
-                float ms = 0.f;
-                hipEventElapsedTime(&ms, e0, e1);
-                if (r) total += ms;
-            }
-            hipEventDestroy(e0); hipEventDestroy(e1);
-            *out_ms = total / reps;
-            break;
-        }
+        // 3000: the hand-scheduled loop (the product's default 256-query kernel), timed like the variants above;
+        // 3000 + bits: its generated timing ablations with the whole-loop cycle count (=> the shader clock of the launch)
+#define RR_FLTQA_CASE(b) case 3000 + (b): *out_ms = rr_debug_time_fltq_asm<(b)>(ix, st, reps); break;
+        RR_FLTQA_CASE(0) RR_FLTQA_CASE(128) RR_FLTQA_CASE(1) RR_FLTQA_CASE(2) RR_FLTQA_CASE(3) RR_FLTQA_CASE(4) RR_FLTQA_CASE(8)
+        RR_FLTQA_CASE(64) RR_FLTQA_CASE(66)
+#undef RR_FLTQA_CASE
         case 400:
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");
             *out_ms = rr_debug_time_flt<192 | 2, true>(ix, st, reps);

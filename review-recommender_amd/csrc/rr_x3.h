@@ -84,6 +84,19 @@ __device__ __forceinline__ float rr_flt_gap_step(const float* __restrict__ eps, 
     return e < 3.0e38f ? 0.5f * e : 0.f;
 }
 
+// The 4-bit gap code of an 8-row M-tile: how far its maximum e sits below the 32-row tile's maximum m (m >= e), in units
+// of `step` (inv_step = 0.9999 / step), ROUNDED DOWN on a two-slope scale: codes 0..7 = [0, 8) steps one step each,
+// 8..15 = [8, 24) steps two steps each, 15 = "at least 22 steps" (an ordinary M-tile next to a top row sits ~60 steps
+// below it and must not be opened with it).  Four instructions: the code is bits 20..23 of the float 8 + gap (clamped
+// below 32): three mantissa bits and the low exponent bit.  inf - inf = NaN comes out as 15: the decoded bound
+// m - 22 steps is then still +-inf, what the M-tile holds.  rr_flt_gap_steps() is the decoder (rr_select_mtiles).
+__device__ __forceinline__ uint32_t rr_flt_gap_code(float m, float e, float inv_step) {
+    float g8 = __builtin_fmaf(m - e, inv_step, 8.0f);
+    asm("v_min_f32 %0, 0x41ffeb85, %0" : "+v"(g8));          // min(g8, 31.99): the other operand for a NaN
+    return (__float_as_uint(g8) >> 20) & 15u;
+}
+__device__ __forceinline__ float rr_flt_gap_steps(uint32_t code) { return code < 8u ? (float)code : (float)(2u * code - 8u); }
+
 // NaN scores and pad rows rank last (rows row0 .. row0+3 of one query)
 __device__ __forceinline__ f32x4 rr_x3_canon(f32x4 v, int64_t row0, int64_t n_rows) {
     v.x = (row0 + 0 < n_rows && v.x == v.x) ? v.x : -INFINITY;

@@ -16,6 +16,7 @@ torch is used for device buffers and streams only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -74,6 +75,11 @@ def _torch():
     return torch
 
 
+# RR_NO_KERNEL_COPY=1 (A/B): the batch's small transfers as copy commands (hipMemcpyAsync) instead of through
+# rr_copy_segments_dev / K1 reading pinned queries
+_KERNEL_COPIES = os.environ.get("RR_NO_KERNEL_COPY") is None
+
+
 class StagedTerms:
     """Token ids of a batch already on the device (HybridSearcher.stage_batch)."""
     __slots__ = ("ids", "off", "slot", "n_ids")
@@ -112,8 +118,32 @@ class HybridSearcher:
     def _stream(self):
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
+    def copy_segments(self, pairs) -> None:
+        """ONE kernel launch on the current stream that copies ``src`` into ``dst`` for every (dst, src) pair of tensors
+        (at most four; same shape and dtype; contiguous, or 2-D with contiguous rows).  Either side may be a PINNED host
+        tensor: the bytes then cross PCIe as the kernel's own loads / stores (rr_copy_segments_dev) instead of as one
+        copy command per tensor -- a batch's token ids in, its rows / order / final scores out."""
+        segs = (_lib.CopySeg * len(pairs))()
+        for i, (dst, src) in enumerate(pairs):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError("copy_segments: shape / dtype mismatch")
+            for t in (dst, src):
+                if not t.is_cuda and not t.is_pinned():
+                    raise ValueError("copy_segments: host tensors must be pinned")
+            esz = dst.element_size()
+            if dst.is_contiguous() and src.is_contiguous():
+                rows, row_bytes, dp, sp = 1, dst.numel() * esz, dst.numel() * esz, dst.numel() * esz
+            else:
+                if dst.dim() != 2 or dst.stride(1) != 1 or src.stride(1) != 1:
+                    raise ValueError("copy_segments: tensors must be contiguous or 2-D with contiguous rows")
+                rows, row_bytes = dst.shape[0], dst.shape[1] * esz
+                dp, sp = dst.stride(0) * esz, src.stride(0) * esz
+            segs[i] = _lib.CopySeg(dst.data_ptr(), src.data_ptr(), row_bytes, rows, dp, sp)
+        _lib.check(self.lib.rr_copy_segments_dev(segs, len(pairs), self.device.index, self._stream()), "rr_copy_segments_dev")
+
     def dense_pool(self, q_dev, pool: int, out=None):
-        """K1 on device tensors: (rows int64 (B,pool), scores float32 (B,pool)).
+        """K1 on device tensors: (rows int64 (B,pool), scores float32 (B,pool)).  ``q_dev``: (B, dim) float32 on the
+        device -- or in PINNED host memory (K1's first kernel then reads the queries over PCIe itself: no copy command).
         ``out`` = (rows, scores) tensors to write into (e.g. views of a shard payload)."""
         torch = _torch()
         B = q_dev.shape[0]
@@ -217,7 +247,10 @@ class HybridSearcher:
         if slot["consumed"] is not None:         # (input stream: the K2 launch that read this device buffer last)
             cur.wait_event(slot["consumed"])
             slot["consumed"] = None
-        slot["dev"][:need].copy_(slot["host"][:need], non_blocking=True)
+        if _KERNEL_COPIES:
+            self.copy_segments([(slot["dev"][:need], slot["host"][:need])])
+        else:
+            slot["dev"][:need].copy_(slot["host"][:need], non_blocking=True)
         slot["event"].record(cur)
         return slot["dev"][n_off:n_off + max(n_ids, 1)], slot["dev"][:n_off], slot, n_ids
 

@@ -123,6 +123,13 @@ class ProductIndex:
         _lib.check(_lib.load().rr_index_last_scan_ms(self._h, C.byref(ms)), "rr_index_last_scan_ms")
         return ms.value
 
+    def last_scan_info(self):
+        """(kernel family, variant, queries per launch, MFMA terms, stream element bytes) of the last batched scan launch
+        (rr_index_last_scan_info; family 5 = filter scan, variant 9 = the 256-query query-stationary rr_scan_fltq)."""
+        out = (C.c_int32 * 8)()
+        _lib.check(_lib.load().rr_index_last_scan_info(self._h, out), "rr_index_last_scan_info")
+        return tuple(out[:5])
+
     def select_trace(self):
         """(fast_path_taken, groups_opened, tiles_opened, candidate_rows, then cycle counts of
         the selection's phases) for the first query of the last selection."""

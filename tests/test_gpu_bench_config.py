@@ -101,6 +101,23 @@ class _IdTokenBM25:
 
 def test_one_bench_step_at_1M_products_matches_the_oracle(shard):
     sh, a = shard
+    check_one_bench_step(sh, a, DOCS, (0, 17, 101, 255))
+
+
+def test_one_bench_step_at_10M_products_matches_the_oracle():
+    """The headline configuration itself (BASELINE metric: 10M products, hybrid alpha = 0.5, k = 100, batches of 256):
+    bench.py's own builder at its default size, one whole step checked by properties for every query and against the
+    oracle pipeline for one sampled query of each query set of the scan launch."""
+    dev = torch.device("cuda", 0)
+    docs = 10_000_000
+    sh = build_device_shard(torch, None, docs=docs, rank=0, world=1, dev=dev, vocab=VOCAB, doc_len=40)
+    a = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in sh.bm25_arrays.items()}
+    check_one_bench_step(sh, a, docs, (17, 201))
+    info = sh.index.last_scan_info()
+    assert info[0] == 5 and info[1] == 9 and info[2] == 256, info      # the 256-query launch bench.py's roofline names
+
+
+def check_one_bench_step(sh, a, DOCS, samples):
     w = FusionWeights(w_dense=0.5, w_bm25=0.5, w_rerank=0.0, w_prior=0.0, w_best=0.0, gate_penalty=1.0)
     Q = synth.unit_rows(BATCH, 384, 4321)
     terms = synth.query_terms(BATCH, VOCAB, 99, sh.stats["df"])
@@ -140,7 +157,7 @@ def test_one_bench_step_at_1M_products_matches_the_oracle(shard):
     meta = pd.DataFrame({"sku": skus, "n_reviews": n_out.cpu().numpy(), "avg_stars": s_out.cpu().numpy(),
                          "agg_text": ""})
     bm = _IdTokenBM25(ora)
-    for b in (0, 17, 101, 255):
+    for b in samples:
         sims64 = OD.sims_float64(V, Q[b])
         raw_dense = (V[rows[b]] @ Q[b]).astype(np.float32)
         assert_topk_matches(rows[b], raw_dense, sims64, POOL)

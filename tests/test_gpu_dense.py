@@ -309,9 +309,11 @@ def test_one_million_rows_full_size():
 
 
 def test_ten_million_rows_batched_at_full_size():
-    """BASELINE's headline size (10M x 384 fp32, 15.4 GB), generated on the device in seeded blocks.  The
-    128-query filter path against (a) the single-query scan, bitwise, and (b) a chunked float64 oracle on
-    the host for two of the queries; plus the size-independent properties of every answer."""
+    """BASELINE's headline size (10M x 384 fp32, 15.4 GB), generated on the device in seeded blocks, searched with the
+    headline batch: 256 queries = ONE launch of the query-stationary filter scan rr_scan_fltq (what bench.py times),
+    checked against (a) the single-query scan, bitwise, for queries of both sets, (b) a chunked float64 oracle on the
+    host for queries of both sets, (c) the size-independent properties of every answer; then the 128-query launch
+    (rr_scan_flt16) the same way."""
     import torch
     n, pool = 10_000_000, 150
     mat = torch.empty((n, 384), device="cuda", dtype=torch.float32)
@@ -322,22 +324,35 @@ def test_ten_million_rows_batched_at_full_size():
         mat[s:s + 1_250_000] = blk / blk.norm(dim=1, keepdim=True)
     del blk
     ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=mat.data_ptr(), keepalive=mat)
-    Q = synth.unit_rows(128, 384, 4242)
-    Q[5] = mat[7_654_321].cpu().numpy()                      # a query that is a row: score 1 at that row
+    Q = synth.unit_rows(256, 384, 4242)
+    Q[5] = mat[7_654_321].cpu().numpy()                      # queries that are rows: score 1 at that row
+    Q[200] = mat[9_999_999].cpu().numpy()                    # (the matrix's last row, second query set)
+
+    def f64_scores(q):                                       # float64 oracle, 1.25M rows at a time
+        q64 = torch.from_numpy(q.astype(np.float64)).cuda()
+        return np.concatenate([(mat[s:s + 1_250_000].double() @ q64).cpu().numpy() for s in range(0, n, 1_250_000)])
+
     rows, scores = ix.dense_topk(Q, pool)
+    info = ix.last_scan_info()
+    assert info[0] == 5 and info[1] == 9 and info[2] == 256 and info[4] == 2, info      # rr_scan_fltq over the bf16 plane
     assert ix.select_trace()[0] == 2
     assert rows[5][0] == 7_654_321 and abs(scores[5][0] - 1.0) < 1e-6
+    assert rows[200][0] == 9_999_999 and abs(scores[200][0] - 1.0) < 1e-6
     for i in range(len(Q)):                                  # properties: sorted, distinct, in range
         assert np.all(np.diff(scores[i]) <= 0) and len(set(rows[i].tolist())) == pool
         assert rows[i].min() >= 0 and rows[i].max() < n
-    for i in (0, 5, 127):                                    # bitwise the single-query scan
+    for i in (0, 5, 127, 128, 200, 255):                     # bitwise the single-query scan
         r1, s1 = ix.dense_topk(Q[i:i + 1], pool)
-        assert np.array_equal(r1[0], rows[i]) and np.array_equal(s1[0].view(np.uint32), scores[i].view(np.uint32))
-    for i in (0, 127):                                       # float64 oracle, 1.25M rows at a time
-        q64 = torch.from_numpy(Q[i].astype(np.float64)).cuda()
-        ref = np.concatenate([(mat[s:s + 1_250_000].double() @ q64).cpu().numpy() for s in range(0, n, 1_250_000)])
-        assert_topk_matches(rows[i], scores[i], ref, pool)
+        assert np.array_equal(r1[0], rows[i]) and np.array_equal(s1[0].view(np.uint32), scores[i].view(np.uint32)), i
+    for i in (0, 127, 128, 255):
+        assert_topk_matches(rows[i], scores[i], f64_scores(Q[i]), pool)
+    # the 128-query launch (rr_scan_flt16, store prefilter on at this size): the same answers, bit for bit
+    rows128, scores128 = ix.dense_topk(Q[:128], pool)
+    info = ix.last_scan_info()
+    assert info[0] == 5 and info[1] == 4 and info[4] == 2, info
+    assert np.array_equal(rows128, rows[:128]) and np.array_equal(scores128.view(np.uint32), scores[:128].view(np.uint32))
     ix.close()
+
 
 def test_f32_chain_matrix_core_path_in_a_subprocess():
     """RR_SCAN_F32_CHAIN=1 selects the f32-input MFMA kernels (scores = pure fmaf chains) for

@@ -48,12 +48,11 @@ def default_answer():
     return run_child({})
 
 
-@pytest.mark.parametrize("switch", ["RR_FLTQ_NOASM", "RR_FLTQ_W8", "RR_NO_FLTQ", "RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR",
+@pytest.mark.parametrize("switch", ["RR_FLTQ_NOASM", "RR_NO_FLTQ", "RR_NO_DUAL", "RR_NO_COUPLE", "RR_DUAL_PREFILTER", "RR_NO_PAIR",
                                     "RR_NO_PREFILTER", "RR_NO_SHADOW", "RR_NO_RESCORE_PLANE"])
 def test_switch_gives_the_default_answer(default_answer, switch):
-    """rows AND scores bitwise: every filter path rescores its candidates with the single-query chain.  (RR_SCAN_EXACT is
-    not in the list: it serves with split-operand arithmetic, equal to fp32 rounding -- near-ties may swap; its parity
-    is checked against the oracle in test_gpu_dense.py.)"""
+    """rows AND scores bitwise: every filter path rescores its candidates with the single-query chain.  (RR_SCAN_EXACT
+    serves with split-operand arithmetic, equal to fp32 rounding: test_exact_scan_switch_differs_only_inside_the_tie_band.)"""
     env = {switch: "1"}
     if switch in ("RR_NO_COUPLE", "RR_DUAL_PREFILTER"):
         env["RR_NO_FLTQ"] = "1"                       # these two act on the rr_scan_flt16 form of the two-set launch
@@ -94,3 +93,48 @@ for n in (2_200_000, 1_000_003):
     for _, n, dw, dg, words, groups in lines:
         assert int(words) > 0 and int(groups) > 0
         assert int(dw) == 0 and int(dg) == 0, (n, dw, dg)
+
+
+TIE_CHILD = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from review_recommender_amd.index import ProductIndex
+n, b, pool = %d, %d, %d
+g = torch.Generator(device="cuda"); g.manual_seed(11)
+m = torch.randn((n, 384), device="cuda", generator=g); m /= m.norm(dim=1, keepdim=True)
+ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=m.data_ptr(), keepalive=m)
+q = np.random.default_rng(12).standard_normal((b, 384)).astype(np.float32)
+q /= np.linalg.norm(q, axis=1, keepdims=True)
+rows, sims = ix.dense_topk(q, pool)
+# float64 scores of the returned rows (the matrix is regenerated from the seed in both children: same bits)
+r = torch.from_numpy(rows).cuda()
+s64 = torch.einsum("bpd,bd->bp", m[r].double(), torch.from_numpy(q).cuda().double()).cpu().numpy()
+np.savez(sys.argv[1], rows=rows, sims=sims, s64=s64)
+""" % (ROOT, N_ROWS, BATCH, POOL)
+
+
+def test_exact_scan_switch_differs_only_inside_the_tie_band(tmp_path):
+    """RR_SCAN_EXACT=1 serves a batch with the split-operand scans (fp32-rounding-equal scores, not the per-row chain):
+    its answer may differ from the default's only where float64 cannot tell the rows apart either -- positions whose
+    float64 scores lie within 4e-7 of each other (the parity bar's tie band), scores within 1e-6."""
+    outs = []
+    for name, env in (("default", {}), ("exact", {"RR_SCAN_EXACT": "1"})):
+        f = str(tmp_path / (name + ".npz"))
+        e = dict(os.environ)
+        e.update(env)
+        p = subprocess.run([sys.executable, "-c", TIE_CHILD, f], env=e, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(np.load(f))
+    d, x = outs
+    assert np.abs(d["sims"] - x["sims"]).max() < 1e-6
+    swapped = 0
+    for i in range(BATCH):
+        diff = np.nonzero(d["rows"][i] != x["rows"][i])[0]
+        swapped += len(diff)
+        for j in diff:                                        # the two rows at a differing position are a float64 near-tie
+            assert abs(d["s64"][i][j] - x["s64"][i][j]) < 4e-7, (i, j, d["s64"][i][j], x["s64"][i][j])
+        # and both lists are ordered by float64 score up to that band
+        for o in (d, x):
+            assert np.all(np.diff(o["s64"][i]) < 4e-7), i
+    print(f"RR_SCAN_EXACT: {swapped} of {BATCH * POOL} positions differ, all inside the 4e-7 band")

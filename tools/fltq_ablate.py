@@ -1,7 +1,9 @@
 """Dev tool: what paces rr_scan_fltq (256 queries, query-stationary)?  python tools/fltq_ablate.py [rows] [variants]
 Needs librr_hip_dbg.so (python review-recommender_amd/build.py --debug).  Variants 2000 + bits (stamped) / 1000 + bits:
 bits 1 no LDS-DMA in the loop, 2 no epilogue pieces / stores, 4 no vmcnt wait + barrier, 8 no A reads, 64 pieces from cache,
-256 16x16x32 MFMAs (same MACs; wrong results), 512 epilogue reduced to the tile maxima."""
+256 16x16x32 MFMAs (same MACs; wrong results), 512 epilogue reduced to the tile maxima.  3000 = the hand-scheduled loop
+(the product's kernel), 3000 + bits = its generated ablations with the loop's cycle count (gen_fltq_loop.py --abl: 128 nothing
+ablated, 1 no LDS-DMA, 2 no epilogue, 4 no wait + barrier, 8 no A reads, 64 pieces from cache)."""
 import os, sys; os.environ["RR_DEBUG_HARNESS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C

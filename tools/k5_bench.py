@@ -18,11 +18,13 @@ def main():
     ap.add_argument("--len", type=int, default=512, help="tokens per pair (fixed), or 0 for lengths uniform in [64, 512]")
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
+                    help="bf16 = the fast path (roofline: bf16 MFMA); fp32 = reference precision (fp32-input MFMA, 157 TF/s peak)")
     a = ap.parse_args()
     from review_recommender_amd import synth
     from review_recommender_amd.cross_encoder import CrossEncoder
     sd = synth.bert_state_dict(1, n_layers=a.layers, n_labels=1)
-    ce = CrossEncoder(sd)
+    ce = CrossEncoder(sd, precision=a.precision)
     if a.len:
         seqs = synth.token_pairs(a.pairs, 2, min_len=a.len, max_len=a.len)
     else:
@@ -40,12 +42,15 @@ def main():
         ce.predict_ids(seqs)
         ms.append(ce.model.last_forward_ms())
     t = float(np.median(ms)) * 1e-3
-    print(json.dumps({"pairs": a.pairs, "tokens": int(T), "layers": a.layers, "forward_ms": round(t * 1e3, 3),
+    peak = 2500.0 if a.precision == "bf16" else 157.3
+    if a.precision == "fp32":
+        flops = model_flops                                   # the fp32 mode computes every token of every layer
+    print(json.dumps({"precision": a.precision, "pairs": a.pairs, "tokens": int(T), "layers": a.layers, "forward_ms": round(t * 1e3, 3),
                       "pairs_per_s": round(a.pairs / t, 1), "tokens_per_s": round(T / t, 1),
                       "model_tflop": round(model_flops / 1e12, 4), "executed_tflop": round(flops / 1e12, 4),
                       "achieved_tflops": round(flops / t / 1e12, 2),
-                      "roofline": {"bound": "mfma", "achieved": round(flops / t / 1e12, 2), "peak": 2500.0,
-                                   "unit": "TFLOP/s", "frac": round(flops / t / 2.5e15, 4)}}))
+                      "roofline": {"bound": "mfma", "achieved": round(flops / t / 1e12, 2), "peak": peak,
+                                   "unit": "TFLOP/s", "frac": round(flops / t / (peak * 1e12), 4)}}))
 
 
 if __name__ == "__main__":
