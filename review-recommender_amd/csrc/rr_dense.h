@@ -49,7 +49,8 @@ void rr_scan_events_end(rr_index* ix, int slot, hipStream_t st);
 // Exact top-pool of `nq` queries from the three score levels a scan left in the index scratch.
 // `only_if` (device, one flag per query, may be null): queries whose flag is 0 are skipped.
 void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
-                      float* d_scores, hipStream_t st, const int32_t* only_if = nullptr);
+                      float* d_scores, hipStream_t st, const int32_t* only_if = nullptr, int slices = 1,
+                      int64_t sims_slice = 0, int64_t gmax_slice = 0, int64_t smax_slice = 0);
 // Two-pass selection of the split-operand scan (see rr_select_mtiles in rr_dense.hip).
 #define RR_X3_MCAP 16384         // M-tiles (8 or 16 rows) one query may ask to have rescored
 struct rr_x3_scratch {           // (every array RR_FLT_MAXQ queries long)

@@ -647,7 +647,15 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
     rr_scan_geom G, const float* __restrict__ sims, const float* __restrict__ gmax,
     const uint32_t* __restrict__ smax, int pool, int64_t row_offset,
     int64_t* __restrict__ out_rows, float* __restrict__ out_scores, int32_t* __restrict__ dbg,
-    const int32_t* __restrict__ only_if) {
+    const int32_t* __restrict__ only_if, int n_total, int64_t sims_slice, int64_t gmax_slice, int64_t smax_slice) {
+    if (gridDim.y > 1) {
+        // the sliced fallback (rr_dense_x3w_fallback_all): slice y = queries 64 y .. of the call, its own scratch
+        const int y = blockIdx.y;
+        if (64 * y + (int)blockIdx.x >= n_total) return;
+        only_if += 64 * y;
+        out_rows += (int64_t)64 * y * pool; out_scores += (int64_t)64 * y * pool; dbg += 64 * y * 16;
+        sims += y * sims_slice; gmax += y * gmax_slice; smax += y * smax_slice;
+    }
     if (only_if && !only_if[blockIdx.x]) return;      // fallback launch: this query was served already
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
@@ -1149,9 +1157,12 @@ void rr_scan_events_end(rr_index* ix, int slot, hipStream_t st) {
     if (ix->ring_head - ix->ring_tail > rr_index::kRing) ix->ring_tail = ix->ring_head - rr_index::kRing;
 }
 void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
-                      float* d_scores, hipStream_t st, const int32_t* only_if) {
-    hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
-                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, only_if);
+                      float* d_scores, hipStream_t st, const int32_t* only_if, int slices, int64_t sims_slice,
+                      int64_t gmax_slice, int64_t smax_slice) {
+    const dim3 grid(slices > 1 ? RR_MFMA_MAXQ : nq, slices > 1 ? slices : 1);
+    hipLaunchKernelGGL(rr_select, grid, dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, only_if, nq, sims_slice,
+                       gmax_slice, smax_slice);
 }
 int rr_resident_waves(const void* kernel, int threads, int device) {
     int per_cu = 0, cus = 0;
@@ -1207,7 +1218,7 @@ static int rr_dense_chunk(rr_index* ix, const float* d_q, int nq, int pool, int6
         ix->timing_valid = true;
     }
     hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
-                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr);
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr, nq, (int64_t)0, (int64_t)0, (int64_t)0);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
@@ -1239,7 +1250,7 @@ static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool,
     ix->ring_head++;
     if (ix->ring_head - ix->ring_tail > rr_index::kRing) ix->ring_tail = ix->ring_head - rr_index::kRing;
     hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
-                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr);
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr, nq, (int64_t)0, (int64_t)0, (int64_t)0);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
@@ -1269,7 +1280,10 @@ static int rr_dense_topk_impl(rr_index* ix, const float* d_q_padded, int nq, int
     // (2.4-2.5 ms fp32, 1.3-1.5 ms bf16); from 5 on the matrix-core scan does (2.7-2.9 / 1.8 ms
     // for up to 16 queries, against 3.0 / 2.4 ms for the 8-query VALU scan)
     const int valu_max = mfma_ok ? 4 : 8;
-    int rc = rr_ensure_scratch(ix, (mfma_ok && nq > valu_max) ? RR_MFMA_MAXQ : 8);
+    // (score scratch: one 64-query slice per 64 queries of a filter call -- its flagged queries are served in slices of one
+    //  launch pair, rr_dense_x3w_fallback_all)
+    const int scratch_slots = (int)rr_round_up(nq < RR_SEL_MAXQ ? nq : RR_SEL_MAXQ, RR_MFMA_MAXQ);
+    int rc = rr_ensure_scratch(ix, (mfma_ok && nq > valu_max) ? scratch_slots : 8);
     if (rc) return rc;
     int q0 = 0;
     while (q0 < nq) {
@@ -1353,7 +1367,7 @@ extern "C" int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n
     d_queries = static_cast<const float*>(q_vis);
     rc = rr_scratch_enter(ix, st);
     if (rc) return rc;
-    rc = rr_ensure_scratch(ix, RR_MFMA_MAXQ);
+    rc = rr_ensure_scratch(ix, (int)rr_round_up(n_queries, RR_MFMA_MAXQ));
     if (rc) return rc;
     const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);
     const int64_t total = (int64_t)slots * ix->dim_pad;

@@ -1351,15 +1351,9 @@ static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, 
                        X.mtiles, X.count, X.fb, X.sc, plane_rows, X.tau, X.eps);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st, floor != nullptr);
     RR_HIP_TRY(hipGetLastError());
-    // Flagged queries: the stored-score pass of the split-operand scan, 64 queries at a time; every
-    // launch in it returns at once when no flag of its queries is up.
-    for (int q0 = 0; q0 < nq; q0 += RR_MFMA_MAXQ) {
-        const int n = nq - q0 < RR_MFMA_MAXQ ? nq - q0 : RR_MFMA_MAXQ;
-        const int rc = rr_dense_chunk_x3w_fallback(ix, d_q + (int64_t)q0 * ix->dim_pad, n, pool, d_rows + (int64_t)q0 * pool,
-                                                   d_scores + (int64_t)q0 * pool, X.fb + q0, st);
-        if (rc != RR_OK) return rc;
-    }
-    return RR_OK;
+    // Flagged queries: the stored-score pass of the split-operand scan, 64 queries per slice of ONE pair of launches;
+    // every slice returns at once when no flag of its queries is up.
+    return rr_dense_x3w_fallback_all(ix, d_q, nq, pool, d_rows, d_scores, X.fb, st);
 }
 
 // What phase 1 of a two-phase call (row shards: scan, exchange a bound, select) leaves for phase 2.

@@ -58,8 +58,18 @@ template <int NQ2, bool A_BF16, bool STORE, int DBG = 0>
 __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr_scan_x3w(
     const u32x4* __restrict__ mat, rr_scan_geom G, const u32x4* __restrict__ planes,  // [3][32*NQ2][48] units
     float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax,
-    const int32_t* __restrict__ fallback, int n_flags, const float* __restrict__ raw_q = nullptr) {
+    const int32_t* __restrict__ fallback, int n_flags, const float* __restrict__ raw_q = nullptr,
+    int64_t sims_slice = 0, int64_t gmax_slice = 0, int64_t smax_slice = 0) {
     constexpr int THREADS = (NQ2 == 2 && !(DBG & 32)) ? 512 : 256;   // (DBG bit 5: one wave per SIMD)
+    if (STORE && fallback && gridDim.y > 1) {
+        // ONE launch for the fallback of up to four 64-query blocks (rr_dense_x3w_fallback_all): slice y = blockIdx.y serves
+        // queries 64 y .. of the call with its own flags, query vectors and score / maxima scratch
+        const int y = blockIdx.y;
+        fallback += 64 * y;
+        n_flags = n_flags - 64 * y < 64 ? n_flags - 64 * y : 64;
+        raw_q += (int64_t)y * 64 * 384;
+        sims += y * sims_slice; gmax += y * gmax_slice; smax += y * smax_slice;
+    }
     if (STORE && fallback) {
         int any = 0;
         for (int i = 0; i < n_flags; ++i) any |= fallback[i];
@@ -495,6 +505,34 @@ static int rr_x3w_fallback_t(rr_index* ix, const float* d_q, int nq, int pool, i
     hipLaunchKernelGGL((rr_scan_x3w<NQ2, A_BF16, true>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G,
                        reinterpret_cast<const u32x4*>(planes), ix->d_sims, ix->d_gmax, ix->d_smax, flags, nq, d_q);
     rr_launch_select(ix, G, nq, pool, d_rows, d_scores, st, flags);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
+// The fallback of a whole filter call (<= 256 queries) as TWO launches instead of two per 64-query block: slice y of the
+// grids serves queries 64 y .. 64 y + 63 with its own score / maxima scratch (rr_ensure_scratch sizes d_sims for the call;
+// d_gmax / d_smax hold four slices as they are).  Every slice returns at once when none of its flags is up.
+int rr_dense_x3w_fallback_all(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows, float* d_scores,
+                              const int32_t* flags, hipStream_t st) {
+    const bool b = ix->dtype == RR_DTYPE_BF16;
+    const int slices = (nq + RR_MFMA_MAXQ - 1) / RR_MFMA_MAXQ;
+    RR_REQUIRE(slices >= 1 && slices <= 4 && ix->scratch_q >= slices * RR_MFMA_MAXQ, "fallback scratch holds %d query slots, %d wanted",
+               ix->scratch_q, slices * RR_MFMA_MAXQ);
+    static int waves[2] = {0, 0};
+    if (!waves[b]) waves[b] = b ? rr_resident_waves((const void*)rr_scan_x3w<2, true, true>, 512, ix->device)
+                                : rr_resident_waves((const void*)rr_scan_x3w<2, false, true>, 512, ix->device);
+    rr_scan_geom G = rr_make_geom(ix, waves[b] / 4);
+    G.qs = 64;
+    const int64_t sims_slice = (int64_t)64 * G.n_pad, gmax_slice = (int64_t)64 * G.n_tiles, smax_slice = (int64_t)64 * RR_MAX_SCAN_WAVES;
+    const dim3 grid((G.n_waves + 7) / 8, slices), block(512);
+    const u32x4* planes = reinterpret_cast<const u32x4*>(ix->d_qplanes);          // (unused: the queries are split in the kernel)
+    if (b)
+        hipLaunchKernelGGL((rr_scan_x3w<2, true, true>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G, planes,
+                           ix->d_sims, ix->d_gmax, ix->d_smax, flags, nq, d_q, sims_slice, gmax_slice, smax_slice);
+    else
+        hipLaunchKernelGGL((rr_scan_x3w<2, false, true>), grid, block, 0, st, reinterpret_cast<const u32x4*>(ix->d_matrix), G, planes,
+                           ix->d_sims, ix->d_gmax, ix->d_smax, flags, nq, d_q, sims_slice, gmax_slice, smax_slice);
+    rr_launch_select(ix, G, nq, pool, d_rows, d_scores, st, flags, slices, sims_slice, gmax_slice, smax_slice);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }

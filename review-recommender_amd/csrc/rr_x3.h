@@ -69,6 +69,10 @@ int rr_dense_chunk_x3w(rr_index* ix, const float* d_q, int nq, int pool, int64_t
 int rr_dense_chunk_x3w_fallback(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                                 float* d_scores, const int32_t* flags, hipStream_t st);
 
+// the same for a whole filter call (<= 256 queries) in two launches (slices of 64 queries, rr_dense_x3w.hip)
+int rr_dense_x3w_fallback_all(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows, float* d_scores,
+                              const int32_t* flags, hipStream_t st);
+
 // Resolution of the filter scan's packed 8-row gaps: half the smallest finite positive error bound of the
 // launch's queries (0: none).  Every wave / workgroup recomputes it from the nq (<= 128) bounds.
 __device__ __forceinline__ float rr_flt_gap_step(const float* __restrict__ eps, int nq) {
