@@ -65,8 +65,12 @@ int rr_index_upload_rows(rr_index* ix, int64_t first_row, int64_t n_rows, const 
  * even, AFTER the normalisation ("round V (RNE) to bf16 once"). */
 int rr_index_upload_rows_f32(rr_index* ix, int64_t first_row, int64_t n_rows, const float* h_rows,
                              float normalize_eps);
-/* Use a caller-owned device matrix (n_rows x dim_padded(), already padded) without copying. */
+/* Use a caller-owned device matrix (n_rows x dim_padded(), already padded) without copying.  The index keeps facts
+ * derived from the matrix content (row-norm bounds of the filter scan, the bf16 filter plane): writes made through this
+ * ABI invalidate them; after writing to an ADOPTED matrix yourself (e.g. an in-place torch update) call
+ * rr_index_matrix_changed, or batched searches filter on the old rows. */
 int rr_index_adopt_device(rr_index* ix, const void* d_matrix);
+int rr_index_matrix_changed(rr_index* ix);
 int rr_index_dim_padded(const rr_index* ix, int32_t* out);
 /* l2_normalize (utils.py:40-44) of every row, in place on the device. */
 int rr_index_l2_normalize(rr_index* ix, float eps);

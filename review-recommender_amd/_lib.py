@@ -70,6 +70,7 @@ PROTOTYPES = {
     "rr_fuse_topk": (C.c_int, [c_vp, P(FuseParams), c_i32] + [c_vp] * 9 + [c_vp] * 3),
     "rr_index_gather_meta_dev": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "rr_copy_segments_dev": (C.c_int, [c_vp, c_i32, c_i32, c_vp]),
+    "rr_index_matrix_changed": (C.c_int, [c_vp]),
     "rr_reviews_create": (C.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_f32, P(c_vp)]),
     "rr_reviews_destroy": (C.c_int, [c_vp]),
     "rr_reviews_best_dev": (C.c_int, [c_vp, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),

@@ -88,6 +88,13 @@ int rr_device_visible(const void* p, const void** out, const char* what) {
     return RR_OK;
 }
 
+extern "C" int rr_index_matrix_changed(rr_index* ix) {
+    RR_REQUIRE(ix != nullptr, "rr_index_matrix_changed: NULL index");
+    std::lock_guard<std::mutex> lk(ix->mu);
+    rr_matrix_written(ix);      // drops the cached row-norm bounds and the bf16 filter plane; both are rebuilt lazily
+    return RR_OK;
+}
+
 extern "C" int rr_copy_segments_dev(const rr_copy_seg* segs, int32_t n_segs, int32_t device, void* stream) {
     RR_REQUIRE(segs && n_segs >= 1 && n_segs <= RR_COPY_MAX_SEGS, "rr_copy_segments_dev: 1 .. %d segments", RR_COPY_MAX_SEGS);
     rr_copy_args A;

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -113,6 +114,9 @@ class HybridSearcher:
         self._q_slots = [{"dev": None, "free": None} for _ in range(4)]
         self._q_next = 0
         self._in = None                       # input stream of stage_batch (created on first use)
+        # the staging rings are shared Python state: one searcher serves every Streamlit session thread (frontend.py), and
+        # the C library's per-handle mutex does not cover slot selection / the pinned buffers
+        self._ring_lock = threading.RLock()
 
     # -------------------------------------------------------------- device steps
     def _stream(self):
@@ -225,6 +229,11 @@ class HybridSearcher:
                     if off[-1] else np.zeros(0, dtype=np.int32))
         n_off, n_ids = off.shape[0], flat.shape[0]
         need = n_off + max(n_ids, 1)
+        with self._ring_lock:
+            return self._stage_terms_locked(off, flat, n_off, n_ids, need)
+
+    def _stage_terms_locked(self, off, flat, n_off, n_ids, need):
+        torch = _torch()
         slot = self._stage_slots[self._stage_next % len(self._stage_slots)]
         self._stage_next += 1
         if slot["host"] is None or slot["host"].numel() < need:
@@ -261,6 +270,11 @@ class HybridSearcher:
         ``release(batch)`` (records when the buffers may be overwritten).  With the answer copied back on a third
         stream, batch i + 1's uploads and batch i - 1's downloads run under batch i's kernels instead of between
         them (~90 us per 256-query batch on one stream)."""
+        torch = _torch()
+        with self._ring_lock:
+            return self._stage_batch_locked(q_host, term_id_lists)
+
+    def _stage_batch_locked(self, q_host, term_id_lists):
         torch = _torch()
         if self._in is None:
             self._in = torch.cuda.Stream(device=self.device)

@@ -123,6 +123,12 @@ class ProductIndex:
         _lib.check(_lib.load().rr_index_last_scan_ms(self._h, C.byref(ms)), "rr_index_last_scan_ms")
         return ms.value
 
+    def matrix_changed(self) -> None:
+        """After writing to a matrix the index ADOPTED (``device_ptr=``) behind its back: drops what the index derived
+        from the old content (row-norm bounds of the filter scan, the bf16 filter plane); rebuilt at the next batched
+        search.  Writes made through the index itself (uploads, l2_normalize) do this on their own."""
+        _lib.check(_lib.load().rr_index_matrix_changed(self._h), "rr_index_matrix_changed")
+
     def last_scan_info(self):
         """(kernel family, variant, queries per launch, MFMA terms, stream element bytes) of the last batched scan launch
         (rr_index_last_scan_info; family 5 = filter scan, variant 9 = the 256-query query-stationary rr_scan_fltq)."""

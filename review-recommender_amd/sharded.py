@@ -74,6 +74,42 @@ class PayloadLayout:
                 "dense": v(self.off_dense, c * 4, torch.float32), "bm25": v(self.off_bm25, c * 4, torch.float32)}
 
 
+class PendingExchange:
+    """An all-gather that has been started (`exchange_start`): `wait()` returns the gathered (world, nbytes) tensor once
+    the CURRENT stream may read it (RCCL: the collective runs on the process group's own stream; wait() makes the
+    current stream wait for it without blocking the host -- kernels enqueued in between run under the collective)."""
+
+    def __init__(self, out, work=None, finish=None):
+        self.out, self.work, self._finish = out, work, finish
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self._finish is not None:
+            self._finish()
+            self._finish = None
+        return self.out
+
+
+def exchange_start(buf, world: int, group=None) -> PendingExchange:
+    """Starts the path's one collective (all-gather of every rank's payload buffer) without waiting for it: what lets
+    batch i's exchange run under K1 of batch i + 1 (ShardedSearcher.submit / finish)."""
+    import torch
+    import torch.distributed as dist
+    out = torch.empty((world, buf.numel()), dtype=torch.uint8, device=buf.device)
+    if world == 1:
+        out[0].copy_(buf)
+        return PendingExchange(out)
+    if dist.get_backend(group) == "nccl":
+        return PendingExchange(out, dist.all_gather_into_tensor(out, buf, group=group, async_op=True))   # RCCL over xGMI
+    if buf.is_cuda:                                               # gloo rehearsal on a GPU box: gloo gathers host tensors
+        host = torch.empty((world, buf.numel()), dtype=torch.uint8)
+        work = dist.all_gather([host[r] for r in range(world)], buf.cpu(), group=group, async_op=True)
+        return PendingExchange(out, work, lambda: out.copy_(host))
+    return PendingExchange(out, dist.all_gather([out[r] for r in range(world)], buf, group=group, async_op=True))
+
+
 def exchange(buf, world: int, group=None):
     """The path's one collective: all-gather of every rank's payload buffer.
     Returns a (world, nbytes) uint8 tensor, identical on every rank."""
@@ -144,6 +180,22 @@ def exchange_scores(local, n_pairs: int, world: int, group=None):
     return torch.cat(parts)
 
 
+@dataclass
+class PendingBatch:
+    """What ShardedSearcher.submit leaves for finish: the batch's parameters, its payload and the started all-gather."""
+    B: int
+    k: int
+    pool: int
+    pool_local: int
+    rr_k: int
+    w: FusionWeights
+    lay: "PayloadLayout"
+    buf: object
+    pending: "PendingExchange"
+    gate_fn: object = None
+    rerank_fn: object = None
+
+
 class ShardedSearcher:
     """K1 + K2 per shard, one all-gather, K3 on the merged pool."""
 
@@ -162,8 +214,11 @@ class ShardedSearcher:
 
     def local_scan(self, q_dev, pool_local: int):
         """Phase 1 of K1 on this rank: the scan and this shard's bound per query (None: the call cannot be split)."""
-        kth = (pool_local + self.world - 1) // self.world        # the shards' kth best rows together: >= pool rows
-        return self.s.dense_scan(q_dev, pool_local, kth)
+        # the shards' kth best rows together hold >= pool rows for any kth >= ceil(pool / world).  A shard is only sure of
+        # ~8 kth rescored rows (kth opened 8-row M-tiles): with kth >= ceil(pool / 8) + 1 its own list of `pool` rows
+        # fills without the exact fallback also at world >= 8 (ceil(150 / 8) = 19 M-tiles = 152 rows would just do)
+        kth = max((pool_local + self.world - 1) // self.world, (pool_local + 7) // 8 + 1)
+        return self.s.dense_scan(q_dev, pool_local, min(kth, pool_local))
 
     def local_payload(self, q_dev, term_id_lists, pool_local: int, bm25_mode: str = "forward", floor=None):
         """K1 (+ the floor exchange when there is more than one shard) + K2 + metadata gather into the payload buffer of
@@ -228,11 +283,46 @@ class ShardedSearcher:
                 gate, rerank = self._pool_columns(rows, B, pool, rr_k, gate_fn, rerank_fn)
             return s.fuse(HybridSearcher.make_params(w, min(k, pool), pool, pool, rr_k), B, rows, dense, bm,
                           None, rerank, None, gate)
+        return self.finish(self.submit(q_dev, term_id_lists, k, weights, pool_floor, bm25_mode, rerank_k, gate_fn, rerank_fn))
+
+    def submit(self, q_dev, term_id_lists, k: int, weights: Optional[FusionWeights] = None, pool_floor: int = 150,
+               bm25_mode: str = "forward", rerank_k: int = 0, gate_fn=None, rerank_fn=None) -> "PendingBatch":
+        """First half of search_batch_dev for row shards: K1 (+ floor exchange) + K2 + metadata gather on this rank, then the
+        payload all-gather is STARTED (exchange_start) and the call returns.  `finish(ticket)` waits for the collective on
+        the stream and runs the merge (K3).  Calling submit(batch i + 1) before finish(batch i) puts batch i's all-gather
+        under batch i + 1's K1 ("pipeline batches so the all-gather of batch i overlaps K1 of batch i+1"):
+
+            t = s.submit(q[0], ...)
+            for i in range(1, n):
+                t_next = s.submit(q[i], ...)
+                res[i - 1] = s.finish(t)
+                t = t_next
+            res[n - 1] = s.finish(t)
+
+        Every answer is bit for bit the one search_batch_dev gives (same kernels, same order per batch)."""
+        w = weights or FusionWeights()
+        B = q_dev.shape[0]
+        pool = min(max(k, rerank_k, pool_floor), self.n_total)
+        pool_local = min(pool, self.s.index.n_rows)
+        rr_k = min(rerank_k, pool)
+        if self.world > 1:
+            assert pool_local == pool, "each shard needs at least `pool` rows"
+        tl = term_id_lists if term_id_lists is not None else [[] for _ in range(B)]
         lay, buf = self.local_payload(q_dev, tl, pool_local, bm25_mode)
-        gathered = exchange(buf, self.world, self.group)
+        pending = exchange_start(buf, self.world, self.group)
+        return PendingBatch(B, k, pool, pool_local, rr_k, w, lay, buf, pending, gate_fn, rerank_fn)
+
+    def finish(self, t: "PendingBatch"):
+        """Second half: the gathered payload is merged and fused (K3; with a gate / reranker: merge, host columns, K3 again)."""
+        import torch
+        s = self.s
+        B, k, pool, pool_local, rr_k, w, lay = t.B, t.k, t.pool, t.pool_local, t.rr_k, t.w, t.lay
+        gate_fn, rerank_fn = t.gate_fn, t.rerank_fn
+        two_pass = gate_fn is not None or (rerank_fn is not None and rr_k > 0)
+        gathered = t.pending.wait()
         base = gathered.data_ptr()
         ptr = lambda off: C.c_void_p(base + off)
-        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
 
         def fuse(k_out, rerank, gate, rr):
             params = HybridSearcher.make_params(w, k_out, pool, self.world * pool_local, rr,
@@ -252,7 +342,7 @@ class ShardedSearcher:
             merged_rows, _, _ = fuse(pool, None, None, 0)           # pass A: the merge alone fixes the pool order
             gate, rerank = self._pool_columns(merged_rows, B, pool, rr_k, gate_fn, rerank_fn)
             res = fuse(min(k, pool), rerank, gate, rr_k)             # pass B: same payload + pool-aligned columns
-        self._keep = (gathered, buf)   # alive until the stream has consumed them
+        self._keep = (gathered, t.buf)   # alive until the stream has consumed them
         return res
 
     def _pool_columns(self, rows_dev, B: int, pool: int, rr_k: int, gate_fn, rerank_fn):

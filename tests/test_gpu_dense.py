@@ -354,6 +354,30 @@ def test_ten_million_rows_batched_at_full_size():
     ix.close()
 
 
+def test_adopted_matrix_changed_behind_the_index():
+    """An adopted device matrix (zero-copy) that the caller rewrites in place: rr_index_matrix_changed drops the cached
+    row-norm bounds and the bf16 filter plane, so the next batched search filters on the NEW rows."""
+    import torch
+    n, pool = 300_000, 150
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    mat = torch.randn((n, 384), device="cuda", generator=g); mat /= mat.norm(dim=1, keepdim=True)
+    ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=mat.data_ptr(), keepalive=mat)
+    Q = synth.unit_rows(32, 384, 5)
+    ix.dense_topk(Q, pool)                                   # builds the plane and the bounds of the old content
+    g.manual_seed(4)
+    new = torch.randn((n, 384), device="cuda", generator=g)
+    mat.copy_(3.0 * new / new.norm(dim=1, keepdim=True))     # in place, behind the index; rows of norm 3 (the old bound: 1)
+    torch.cuda.synchronize()
+    ix.matrix_changed()
+    rows, scores = ix.dense_topk(Q, pool)
+    fresh = ProductIndex(None, n_rows=n, dim=384, device_ptr=mat.data_ptr(), keepalive=mat)
+    want_rows, want_scores = fresh.dense_topk(Q, pool)
+    assert np.array_equal(rows, want_rows) and np.array_equal(scores.view(np.uint32), want_scores.view(np.uint32))
+    r1, s1 = ix.dense_topk(Q[:1], pool)                      # and both equal the single-query scan of the new rows
+    assert np.array_equal(r1[0], rows[0])
+    ix.close(); fresh.close()
+
+
 def test_f32_chain_matrix_core_path_in_a_subprocess():
     """RR_SCAN_F32_CHAIN=1 selects the f32-input MFMA kernels (scores = pure fmaf chains) for
     batches; the switch is read once per process, so the check runs in a child process."""

@@ -226,3 +226,38 @@ def test_shards_select_against_a_corpus_wide_floor(dtype):
     shards[0].s.dense_pool(q_dev[:3], pool)
     with pytest.raises(Exception):
         shards[0].s.dense_select(q_dev, pool, floor)
+
+
+def test_pipelined_submit_finish_equals_the_straight_path_bitwise():
+    """ShardedSearcher.submit / finish (batch i + 1's K1 enqueued before batch i's merge) on the payload path of
+    one GPU: three batches in flight give bit for bit what search_batch_dev gives one at a time -- also with the queries
+    read from PINNED host memory by K1's first kernel and the answer written to pinned memory by one copy kernel."""
+    n, vocab, batch = 60_000, 3000, 200
+    V = synth.unit_rows(n, 384, 71)
+    n_rev, stars = synth.metadata(n, 72)
+    ip, terms, tf, dl = synth.bm25_forward_csr(n, vocab, 30, 73)
+    corpus = BM25Corpus(ip, terms, tf, dl, vocab)
+    sh = ShardedSearcher(build(V, n_rev.astype(np.float64), stars, corpus, 0, n), n, 0, 1)
+    sh.force_payload = True
+    w = FusionWeights(w_dense=0.5, w_bm25=0.5, w_rerank=0.0, w_prior=0.0, w_best=0.0, gate_penalty=1.0)
+    df = np.bincount(terms, minlength=vocab)
+    Qs = [synth.unit_rows(batch, 384, 80 + i) for i in range(3)]
+    tls = [synth.query_terms(batch, vocab, 90 + i, df) for i in range(3)]
+    want = [[t.cpu().numpy() for t in sh.search_batch_dev(torch.from_numpy(Q).cuda(), tl, 100, w)] for Q, tl in zip(Qs, tls)]
+    pins = [torch.from_numpy(Q).pin_memory() for Q in Qs]
+    outs = []
+    ticket = sh.submit(pins[0], tls[0], 100, w)
+    for i in range(1, 3):
+        nxt = sh.submit(pins[i], tls[i], 100, w)
+        outs.append(sh.finish(ticket))
+        ticket = nxt
+    outs.append(sh.finish(ticket))
+    for (rows, cols, order), (wr, wc, wo) in zip(outs, want):
+        p_rows = torch.empty(rows.shape, dtype=rows.dtype).pin_memory()
+        p_final = torch.empty((batch, cols.shape[2]), dtype=cols.dtype).pin_memory()
+        sh.s.copy_segments([(p_rows, rows), (p_final, cols[:, 7, :])])
+        torch.cuda.synchronize()
+        assert np.array_equal(p_rows.numpy(), wr) and np.array_equal(p_final.numpy(), wc[:, 7, :])
+        assert np.array_equal(cols.cpu().numpy(), wc, equal_nan=True) and np.array_equal(order.cpu().numpy(), wo)
+    with pytest.raises(ValueError):
+        sh.s.copy_segments([(torch.empty(4), torch.empty(4, device="cuda"))])      # pageable host memory is refused

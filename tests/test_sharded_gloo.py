@@ -170,3 +170,39 @@ def test_floor_exchange_is_the_elementwise_minimum():
     want = np.array([0.30, 0.23, -np.inf], dtype=np.float32)
     for r in range(world):
         assert np.array_equal(ret[r], want)
+
+
+def _pipeline_worker(rank, world, port, ret):
+    from review_recommender_amd.sharded import exchange_start
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # three batches in flight the way ShardedSearcher.submit / finish pipelines them: batch i + 1's exchange is started
+        # (and "K1 of batch i + 1" -- here: filling the next buffer -- runs) before batch i's gathered blocks are waited for
+        bufs = [torch.full((48,), 10 * i + rank, dtype=torch.uint8) for i in range(3)]
+        got = []
+        pend = exchange_start(bufs[0], world)
+        for i in range(1, 3):
+            nxt = exchange_start(bufs[i], world)
+            got.append(pend.wait().numpy().copy())
+            pend = nxt
+        got.append(pend.wait().numpy().copy())
+        assert pend.wait() is pend.out                      # a second wait is a no-op
+        ret[rank] = got
+    finally:
+        dist.destroy_process_group()
+
+
+def test_started_exchanges_complete_in_order_and_match_the_blocking_form():
+    """"pipeline batches so the all-gather of batch i overlaps K1 of batch i+1" -- exchange_start returns at
+    once, wait() hands back the gathered blocks; several may be in flight; every rank sees every batch's blocks."""
+    world = 2
+    port = free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_pipeline_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        for i in range(3):
+            g = ret[r][i]
+            assert g.shape == (world, 48)
+            assert np.all(g[0] == 10 * i) and np.all(g[1] == 10 * i + 1)
