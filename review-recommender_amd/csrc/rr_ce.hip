@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256) void ce_add_ln_f32(const float* __restrict__ y
 }
 
 // softmax(Q K^T / sqrt(32)) V of one (sequence, head), fp32: K and V of the head in LDS, one query per thread (its 32
-// dims and 32 outputs in registers), exact two-pass softmax (maximum, then exp and sums).
+// dims and 32 outputs in registers), fp32 softmax with exact exp.
 __global__ __launch_bounds__(256) void ce_attention_f32(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                         float* __restrict__ ctx, float scale) {
     extern __shared__ float kv[];                             // K [S][32], V [S][32]
@@ -868,22 +868,40 @@ __global__ __launch_bounds__(256) void ce_attention_f32(const float* __restrict_
         const float* qp = qkv + (int64_t)(t0 + qi) * (3 * CE_H) + head * CE_HD;
 #pragma unroll
         for (int d = 0; d < CE_HD; ++d) { q[d] = qp[d]; o[d] = 0.f; }
-        float mx = -INFINITY;
-        for (int j = 0; j < S; ++j) {
-            float s = 0.f;
+        // keys in chunks of 32: the chunk's scores once, ONE rescaling of the running sums per chunk (online softmax in
+        // fp32: exp(s - m) with the running maximum m; differs from the two-pass form by fp32 rounding only)
+        float mx = -INFINITY, l = 0.f;
+        for (int j0 = 0; j0 < S; j0 += 32) {
+            const int nj = S - j0 < 32 ? S - j0 : 32;
+            float sj[32];
+            float cm = -INFINITY;
 #pragma unroll
-            for (int d = 0; d < CE_HD; ++d) s = __builtin_fmaf(q[d], Ks[j * CE_HD + d], s);
-            mx = fmaxf(mx, s * scale);
-        }
-        float l = 0.f;
-        for (int j = 0; j < S; ++j) {
-            float s = 0.f;
+            for (int jj = 0; jj < 32; ++jj) {
+                float s = 0.f;
+                if (jj < nj) {
 #pragma unroll
-            for (int d = 0; d < CE_HD; ++d) s = __builtin_fmaf(q[d], Ks[j * CE_HD + d], s);
-            const float p = expf(s * scale - mx);
-            l += p;
+                    for (int d = 0; d < CE_HD; ++d) s = __builtin_fmaf(q[d], Ks[(j0 + jj) * CE_HD + d], s);
+                    s *= scale;
+                    cm = fmaxf(cm, s);
+                } else s = -INFINITY;
+                sj[jj] = s;
+            }
+            if (cm > mx) {
+                const float c = expf(mx - cm);         // (first chunk: exp(-inf) = 0 on zero sums)
+                l *= c;
 #pragma unroll
-            for (int d = 0; d < CE_HD; ++d) o[d] = __builtin_fmaf(p, Vs[j * CE_HD + d], o[d]);
+                for (int d = 0; d < CE_HD; ++d) o[d] *= c;
+                mx = cm;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) {
+                if (jj < nj) {
+                    const float p = expf(sj[jj] - mx);
+                    l += p;
+#pragma unroll
+                    for (int d = 0; d < CE_HD; ++d) o[d] = __builtin_fmaf(p, Vs[(j0 + jj) * CE_HD + d], o[d]);
+                }
+            }
         }
         const float inv = 1.0f / l;
         float* op = ctx + (int64_t)(t0 + qi) * CE_H + head * CE_HD;

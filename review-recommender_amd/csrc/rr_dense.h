@@ -103,3 +103,8 @@ int rr_store_rows_bf16(rr_index* ix, int64_t first_row, int64_t n, float* d_rows
 
 // rr_api.hip: the address a kernel may use for p (device memory, or pinned host memory through its mapping)
 int rr_device_visible(const void* p, const void** out, const char* what);
+
+// rr_dense_flt.hip: rr_pad_queries and rr_flt_prep_queries in ONE launch (the front of a batched filter call): the padded
+// fp32 queries into ix->d_q plus their bf16 planes and error bounds.  Returns RR_FLT_NO_BOUND (nothing launched) when the
+// matrix has no finite row-norm bound: the caller pads the plain way.
+int rr_flt_pad_prep(rr_index* ix, const float* d_queries, int nq, int slots, hipStream_t st);

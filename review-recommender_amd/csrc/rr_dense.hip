@@ -817,10 +817,26 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
             // (row shards, DESIGN.md section 5: a row of the corpus-wide top-pool has score >= floor, hence filter score
             //  >= floor - e: nothing below floor - 1.05 e has to be opened, whatever this shard's own threshold says)
             const float fl = (floor && eps) ? floor[Q] - 1.05f * e : -INFINITY;
-            tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2, eps ? 2.05f * e : -1.f, &open,
-                                     fl == fl ? rr_f2key(fl) : 0u);
-            if (!eps) open = tau;
-            else tau = rr_f2key(rr_key2f(tau) - 1.02f * e);
+            if (fl > -3.0e38f) {
+                // A finite corpus-wide floor F (a lower bound of the corpus-wide pool-th best SCORE): every row that can be in
+                // the merged answer has score >= F, filter score >= F - e.  No threshold search of this shard's own: groups and
+                // M-tiles are opened down to F - 1.05 e and the row cut is F itself (rows below it may come back as -inf:
+                // they only fill this shard's list up, the merge never takes them).
+                open = rr_f2key(fl);
+                if (open == 0u) open = 1u;
+                for (int i = tid; i < ng; i += RR_SEL_THREADS) {
+                    if (group_key_at(i) >= open) {
+                        const uint32_t slot = atomicAdd(&counters[0], 1u);
+                        if (slot < RR_SEL_LCAP) list2[slot] = (uint32_t)i;
+                    }
+                }
+                __syncthreads();
+                tau = rr_f2key(floor[Q]);
+            } else {
+                tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2, eps ? 2.05f * e : -1.f, &open, 0u);
+                if (!eps) open = tau;
+                else tau = rr_f2key(rr_key2f(tau) - 1.02f * e);
+            }
             if (tau == 0u) tau = 1u;
             if (counters[0] > RR_SEL_LCAP) ok = false;
         }
@@ -1371,8 +1387,10 @@ extern "C" int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n
     if (rc) return rc;
     const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);
     const int64_t total = (int64_t)slots * ix->dim_pad;
-    hipLaunchKernelGGL(rr_pad_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       d_queries, ix->d_q, n_queries, ix->dim, ix->dim_pad, slots);
+    // (padding + planes + bounds in one launch; without a finite row-norm bound the plain padding, and the call is declined below)
+    if (rr_flt_pad_prep(ix, d_queries, n_queries, slots, st) != RR_OK)
+        hipLaunchKernelGGL(rr_pad_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           d_queries, ix->d_q, n_queries, ix->dim, ix->dim_pad, slots);
     rc = rr_dense_chunk_flt(ix, ix->d_q, n_queries, pool, nullptr, nullptr, st, 1, kth, d_bound, nullptr);
     if (rc == RR_FLT_NO_BOUND || rc == RR_FLT_SMALL) return rr_scratch_leave(ix, st);     // not applied
     if (rc) return rc;
@@ -1421,9 +1439,15 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
     if (rc) return rc;
     const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);   // kernels read whole query tiles
     const int64_t total = (int64_t)slots * ix->dim_pad;
-    hipLaunchKernelGGL(rr_pad_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       d_queries, ix->d_q, n_queries, ix->dim, ix->dim_pad, slots);
+    // a call the batched filter path will serve in one chunk: padding + bf16 planes + bounds in ONE launch
+    static const bool plain_front = getenv("RR_SCAN_EXACT") != nullptr || getenv("RR_SCAN_F32_CHAIN") != nullptr;
+    const bool filter_call = ix->dim_pad == 384 && ix->n_rows >= 64 && n_queries > 4 && n_queries <= RR_SEL_MAXQ && !plain_front &&
+                             ix->scan_mode == RR_SCAN_MODE_DEFAULT && (ix->n_rows + 63) / 64 >= 8 * (int64_t)pool;
+    if (!filter_call || rr_flt_pad_prep(ix, d_queries, n_queries, slots, st) != RR_OK)
+        hipLaunchKernelGGL(rr_pad_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           d_queries, ix->d_q, n_queries, ix->dim, ix->dim_pad, slots);
     rc = rr_dense_topk_impl(ix, ix->d_q, n_queries, pool, d_out_rows, d_out_scores, st);
+    ix->flt_prep_fresh = false;
     if (rc) return rc;
     return rr_scratch_leave(ix, st);
 }

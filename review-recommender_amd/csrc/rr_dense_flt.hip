@@ -71,6 +71,34 @@ __global__ __launch_bounds__(64) void rr_flt_prep_queries(const float* __restric
         eps[slot] = 1.01f * (B.row_delta * sqrtf(sr) + B.row_norm * sqrtf(sd) + 6.1035156e-5f * B.row_norm * sqrtf(ss));
 }
 
+// The same with the padding of the caller's queries in front (rr_pad_queries): slot < nq reads the caller's row (nq x dim,
+// device memory or mapped pinned host memory), the rest is zeros; the padded fp32 row goes to `padded` as well.
+__global__ __launch_bounds__(64) void rr_flt_pad_prep_queries(const float* __restrict__ src, int nq, int dim, float* __restrict__ padded,
+                                                              unsigned short* __restrict__ plane, float* __restrict__ eps, rr_flt_bounds B) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    float ss = 0.f, sr = 0.f, sd = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pos = lane + 64 * i;
+        const float x = (slot < nq && pos < dim) ? src[(int64_t)slot * dim + pos] : 0.f;
+        padded[(int64_t)slot * 384 + pos] = x;
+        const __bf16 r = (__bf16)x;                                // round to nearest even
+        const float xr = (float)r, d = x - xr;
+        ss = __builtin_fmaf(x, x, ss);
+        sr = __builtin_fmaf(xr, xr, sr);
+        sd = __builtin_fmaf(d, d, sd);
+        plane[(int64_t)slot * 384 + pos] = __builtin_bit_cast(unsigned short, r);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        ss += __shfl_xor(ss, m, 64);
+        sr += __shfl_xor(sr, m, 64);
+        sd += __shfl_xor(sd, m, 64);
+    }
+    if (lane == 0)        // (the bound of rr_flt_prep_queries, term for term)
+        eps[slot] = 1.01f * (B.row_delta * sqrtf(sr) + B.row_norm * sqrtf(sd) + 6.1035156e-5f * B.row_norm * sqrtf(ss));
+}
+
 // max over rows of ||a|| and of ||a - bf16(a)||, as the bits of non-negative floats (atomicMax on uint).
 // 16 lanes per row, 16-byte loads (four rows per wave instruction), 64 rows per wave.
 template <bool A_BF16>
@@ -1287,7 +1315,7 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
     float* eps = X.eps + set * RR_FLT_MAXQ;
     float* gmax = ix->d_gmax + set * rr_flt_mmax_set_stride(G);
     uint32_t* smax = ix->d_smax + set * rr_flt_smax_set_stride();
-    if (prep_sets)
+    if (prep_sets && !ix->flt_prep_fresh)         // (rr_flt_pad_prep has done it with the padding, for every slot of the call)
         hipLaunchKernelGGL(rr_flt_prep_queries, dim3(QN * prep_sets), dim3(64), 0, st, d_q, plane, eps, bounds);   // (planes in memory order)
     const dim3 grid((G.n_waves + THREADS / 64 - 1) / (THREADS / 64)), block(THREADS);
     // Store prefilter (bf16 stream, >= 2M rows): a 1/64 tile sample gives every query sigma = its m-th largest sampled
@@ -1342,10 +1370,10 @@ static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, 
     const rr_x3_scratch X = rr_x3_scratch_of(ix);
     const int nq = nq_a + nq_b;
     rr_launch_select_mtiles(ix, G, nq_a, pool, st, X.eps, sigma, nq_b, rr_flt_mmax_set_stride(G), rr_flt_smax_set_stride(), floor);
-    // (the plane pre-scoring of the rescored rows: fp32 storage with a valid plane, and not in floor mode, where rows
-    //  below the shard's own cut may be taken to fill its list up and need their exact scores)
+    // (the plane pre-scoring of the rescored rows: fp32 storage with a valid plane.  Under a corpus-wide floor the row cut is
+    //  the floor: rows below it come back as -inf and only fill the shard's list up -- the merge never takes them)
     static const bool no_pre = getenv("RR_NO_RESCORE_PLANE") != nullptr;
-    const u32x4* plane_rows = (!ROWS_BF16 && ix->shadow_valid && ix->d_shadow && !floor && !no_pre)
+    const u32x4* plane_rows = (!ROWS_BF16 && ix->shadow_valid && ix->d_shadow && !no_pre)
                                   ? reinterpret_cast<const u32x4*>(ix->d_shadow) : nullptr;
     hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
                        X.mtiles, X.count, X.fb, X.sc, plane_rows, X.tau, X.eps);
@@ -1468,8 +1496,30 @@ static int rr_dense_pair_flt_t(rr_index* ix, const void* scan_mat, const float* 
     return rr_flt_after_scan<ROWS_BF16>(ix, G, d_q, nq_a, nq_b, pool, d_rows, d_scores, sg0, st, ph);
 }
 
+int rr_flt_pad_prep(rr_index* ix, const float* d_queries, int nq, int slots, hipStream_t st) {
+    ix->flt_prep_fresh = false;
+    rr_flt_bounds nb;
+    const int rc = rr_flt_get_bounds(ix, st, &nb);
+    if (rc != RR_OK) return rc;
+    if (!(nb.row_norm < 3.0e18f) || slots > RR_SEL_MAXQ || ix->dim_pad != 384) return RR_FLT_NO_BOUND;
+    const rr_x3_scratch X = rr_x3_scratch_of(ix);
+    hipLaunchKernelGGL(rr_flt_pad_prep_queries, dim3(slots), dim3(64), 0, st, d_queries, nq, ix->dim, ix->d_q,
+                       reinterpret_cast<unsigned short*>(ix->d_qplanes), X.eps, nb);
+    RR_HIP_TRY(hipGetLastError());
+    ix->flt_prep_fresh = true;
+    return RR_OK;
+}
+
+// (every exit of a filter call -- served or declined -- leaves the planes "not fresh": they belong to ONE call)
+struct rr_flt_fresh_guard {
+    rr_index* ix;
+    ~rr_flt_fresh_guard() { ix->flt_prep_fresh = false; }
+};
+
 int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                        float* d_scores, hipStream_t st, int phase, int kth, float* d_bound, const float* d_floor) {
+    rr_flt_fresh_guard fresh_guard{ix};
+    if (d_q != ix->d_q) ix->flt_prep_fresh = false;       // a later chunk of a long call: its planes are not the prepared ones
     if (phase == 2) {
         // selection of the scan a phase-1 call left behind (same queries, same pool), with the exchanged floor
         rr_flt_pending* p = rr_flt_pending_of(ix);

@@ -167,7 +167,7 @@ class HybridSearcher:
         the call cannot be split (then use dense_pool)."""
         torch = _torch()
         B = q_dev.shape[0]
-        bound = torch.full((B,), float("-inf"), dtype=torch.float32, device=self.device)
+        bound = torch.empty((B,), dtype=torch.float32, device=self.device)      # (written in full whenever `applied`)
         applied = C.c_int32(0)
         _lib.check(self.lib.rr_dense_scan_dev(self.index.handle, C.c_void_p(q_dev.data_ptr()), B, pool, int(kth),
                                               C.c_void_p(bound.data_ptr()), C.byref(applied), self._stream()),

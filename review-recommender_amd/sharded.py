@@ -220,7 +220,7 @@ class ShardedSearcher:
         kth = max((pool_local + self.world - 1) // self.world, (pool_local + 7) // 8 + 1)
         return self.s.dense_scan(q_dev, pool_local, min(kth, pool_local))
 
-    def local_payload(self, q_dev, term_id_lists, pool_local: int, bm25_mode: str = "forward", floor=None):
+    def local_payload(self, q_dev, term_id_lists, pool_local: int, bm25_mode: str = "forward", floor=None, buf=None):
         """K1 (+ the floor exchange when there is more than one shard) + K2 + metadata gather into the payload buffer of
         this rank.  ``floor``: tests that play several shards in one process pass the minimum they formed themselves
         (after calling local_scan on every shard); ``False`` = plain K1."""
@@ -228,7 +228,8 @@ class ShardedSearcher:
         s = self.s
         B = q_dev.shape[0]
         lay = PayloadLayout(B, pool_local)
-        buf = torch.empty(lay.nbytes, dtype=torch.uint8, device=s.device)
+        if buf is None:                 # (``buf``: a caller-owned uint8 buffer of lay.nbytes to build the payload in)
+            buf = torch.empty(lay.nbytes, dtype=torch.uint8, device=s.device)
         v = lay.views(buf)
         import torch.distributed as dist
         if floor is None and self.world > 1 and self.use_floor and dist.is_available() and dist.is_initialized():

@@ -46,14 +46,13 @@ def step(timed=None):
     bounds = [sh.sharded.local_scan(q_pin, POOL) for sh in shards]                 # phase 1 of K1 on every rank
     floor = torch.stack(bounds).min(dim=0).values                                   # (= the all-reduce(MIN) of B floats)
     if timed is not None: ev[1].record()
-    lay, bufs = None, []
-    for sh in shards:                                                               # phase 2 + K2 + metadata -> payload
-        lay, buf = sh.sharded.local_payload(q_pin, terms, POOL, floor=floor)
-        bufs.append(buf)
+    lay = PayloadLayout(B, POOL)
+    gathered = torch.empty((world, lay.nbytes), dtype=torch.uint8, device=dev)     # (= what the all-gather leaves)
+    for r, sh in enumerate(shards):                                                 # phase 2 + K2 + metadata -> payload
+        sh.sharded.local_payload(q_pin, terms, POOL, floor=floor, buf=gathered[r])
     if timed is not None: ev[2].record()
-    gathered = torch.stack(bufs)                                                    # (= what the all-gather leaves)
     s0 = shards[0].sharded
-    rows, cols, order = s0.finish(PendingBatch(B, K, POOL, POOL, 0, w, lay, bufs[0], PendingExchange(gathered)))
+    rows, cols, order = s0.finish(PendingBatch(B, K, POOL, POOL, 0, w, lay, gathered[0], PendingExchange(gathered)))
     s0.s.copy_segments([(pins[0], rows), (pins[1], order), (pins[2], cols[:, 7, :])])
     if timed is not None:
         ev[3].record()
