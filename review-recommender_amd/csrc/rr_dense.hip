@@ -951,7 +951,10 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
     const uint32_t tau = tau_of[q];
     const int sh = G.mm_pairs == 3 ? 3 : 4;           // rows per listed M-tile: 8 or 16
     const int n1 = count[q] << sh;
-    for (int i = tid; i < n1; i += RR_SEL_THREADS) {
+    // (row shards under a corpus-wide floor: the best `pool` of ALL rescored rows is the answer whether or not `pool` of them
+    //  reach the cut -- one pass when they fit)
+    const bool all_rows = floor_mode && (uint32_t)n1 <= RR_SEL_CCAP / 2;
+    for (int i = tid; i < n1 && !all_rows; i += RR_SEL_THREADS) {
         const int64_t at = (int64_t)q * RR_X3_MCAP + (i >> sh);
         const int r = i & ((1 << sh) - 1);
         const uint32_t row = (mtiles[at] << sh) + (uint32_t)r;
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
     }
     __syncthreads();
     uint32_t n_cand = counters[0];
-    if (floor_mode && n_cand < (uint32_t)pool && (uint32_t)n1 <= RR_SEL_CCAP / 2) {
+    if (all_rows || (floor_mode && n_cand < (uint32_t)pool && (uint32_t)n1 <= RR_SEL_CCAP / 2)) {
         // Row shards with a corpus-wide floor: fewer M-tiles were opened than this shard's own top-pool needs, so fewer
         // than `pool` rows may reach its own cut.  Every row of the corpus-wide top-pool that lives here IS among the
         // rescored rows; the list is filled up with the best of the other rescored rows (exact scores, below the

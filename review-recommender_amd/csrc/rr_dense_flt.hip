@@ -1255,6 +1255,9 @@ static rr_scan_geom rr_fltq_geom(rr_index* ix) {
     G.gpw = RR_MAX_SCAN_WAVES / G.n_waves < 32 ? (RR_MAX_SCAN_WAVES / G.n_waves < 1 ? 1 : RR_MAX_SCAN_WAVES / G.n_waves) : 32;
     if (G.gpw > G.tiles_per_wave) G.gpw = (int32_t)G.tiles_per_wave;
     G.tiles_per_group = (G.tiles_per_wave + G.gpw - 1) / G.gpw;
+    // (a group's end takes the wave out of the hand-scheduled loop -- accumulators copied out and in, the matrix pipe drained --:
+    //  at least 16 M-tiles per group, which a small shard would otherwise undercut; the selection only needs > pool groups)
+    if (G.tiles_per_group < 8 && (int64_t)G.n_waves * ((G.tiles_per_wave + 7) / 8) > 2048) G.tiles_per_group = 8;
     G.tiles_per_group += G.tiles_per_group & 1;       // even: a group closes on a multiple of four M-tiles (the unrolled loop)
     G.gpw = (int32_t)((G.tiles_per_wave + G.tiles_per_group - 1) / G.tiles_per_group);
     return G;

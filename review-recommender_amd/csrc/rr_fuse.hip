@@ -215,20 +215,29 @@ __global__ __launch_bounds__(RR_FUSE_THREADS) void rr_fuse(
             // equal keys -- the same row offered twice -- go to the earlier list) -- no sort, no barrier per stage: 73 -> ~30 us
             // for 8 x 150 candidates.  The places 0 .. pool - 1 are each taken exactly once.
             const int nl = ncand / cpr;
+            int top = 1;
+            while (top * 2 <= cpr) top *= 2;           // largest power of two <= cpr
             for (int i = tid; i < ncand; i += RR_FUSE_THREADS) {
                 const uint64_t key = keys[i];
                 const int r = i / cpr;
                 int place = i - r * cpr;
-                for (int r2 = 0; r2 < nl; ++r2) {
-                    if (r2 == r) continue;
-                    const uint64_t* lst = keys + r2 * cpr;
-                    int lo = 0, hi = cpr;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        const bool before = r2 < r ? lst[mid] >= key : lst[mid] > key;
-                        if (before) lo = mid + 1; else hi = mid;
+                // branch-free searches, eight lists at a time: their LDS reads are independent and overlap
+                for (int r0 = 0; r0 < nl; r0 += 8) {
+                    int lo[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) lo[u] = 0;
+                    for (int step = top; step >= 1; step >>= 1) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int r2 = r0 + u < nl ? r0 + u : nl - 1;
+                            const int mid = lo[u] + step;            // lo = how many keys of the list come before this one
+                            const uint64_t v = keys[r2 * cpr + (mid <= cpr ? mid - 1 : cpr - 1)];
+                            const bool before = r2 < r ? v >= key : v > key;
+                            lo[u] = (mid <= cpr && before) ? mid : lo[u];
+                        }
                     }
-                    place += lo;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) place += (r0 + u < nl && r0 + u != r) ? lo[u] : 0;
                 }
                 if (place < pool) c_src[place] = i;
             }
