@@ -503,8 +503,9 @@ def main():
         # corrected as MI355X_MICROARCH.md prescribes), for this kernel at this many queries per launch on 10M
         # rows; the same bytes-per-row ratio is applied to this run's rows.  null without such a summary.
         traffic = None
-        # (r02: the 128-query scan over the bf16 filter plane with the store prefilter; r01: the same scan over fp32 rows)
-        for tag in (("r02",) if info["elem_bytes"] == 2 else ("r01",)):
+        # (r03: the 256-query rr_scan_fltq on 16x16x32 MFMAs; r02: the 128-query scan over the bf16 filter plane with the store
+        #  prefilter; r01: the same scan over fp32 rows -- the newest summary of this launch shape wins)
+        for tag in (("r03", "r02") if info["elem_bytes"] == 2 else ("r01",)):
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_scan_b{qpl}_10M.json")
             if os.path.exists(pmc) and args.dtype == "f32":
                 with open(pmc) as f:

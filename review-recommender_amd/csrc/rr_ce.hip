@@ -756,21 +756,23 @@ __global__ void ce_to_bf16(const float* __restrict__ src, unsigned short* __rest
 // parity mode, ~10x the time of the bf16 path.
 typedef float f32x16r __attribute__((ext_vector_type(16)));
 
-// out[M][N] = A[M][K] W[N][K]^T + bias (+ exact GELU); A, W, out fp32 row-major; N % 128 == 0, K % 8 == 0.
-// Workgroup = 4 waves (2 x 2), 128 x 128 outputs, wave = 64 x 64 = 2 x 2 MFMA tiles; K tiles of 8 through LDS, stored
+// out[M][N] = A[M][K] W[N][K]^T + bias (+ exact GELU); A, W, out fp32 row-major; N % 128 == 0, K % 16 == 0.
+// Workgroup = 4 waves (2 x 2), 128 x 128 outputs, wave = 64 x 64 = 2 x 2 MFMA tiles; K tiles of 16 through LDS, stored
 // k-major ([k][row], rows padded to 132 floats: conflict-free for the ds_write_b32 of the staging and the ds_read_b32 of
-// the operands).  MFMA operands: A lane l = row (l & 31), k = l >> 5; B lane l = column (l & 31), k = l >> 5; C register
+// the operands).  K % 16 == 0.  MFMA operands: A lane l = row (l & 31), k = l >> 5; B lane l = column (l & 31), k = l >> 5; C register
 // 4 g + i = row 8 g + 4 (l >> 5) + i, column l & 31.
 #define CE_F32_LD 132
 template <bool GELU>
 __global__ __launch_bounds__(256) void ce_gemm_f32(const float* __restrict__ A, const float* __restrict__ W,
                                                    const float* __restrict__ bias, int M, int N, int K,
                                                    float* __restrict__ out) {
-    __shared__ float As[8 * CE_F32_LD], Ws[8 * CE_F32_LD];
+    // K tiles of 16, k-major in LDS; the next tile's global loads are issued before the current tile's MFMAs (their latency
+    // runs under 32 MFMAs per wave)
+    __shared__ float As[16 * CE_F32_LD], Ws[16 * CE_F32_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int srow = tid >> 1, skq = tid & 1;                 // staging: row of the tile, which float4 of its 8 k
+    const int srow = tid >> 1, skq = tid & 1;                 // staging: row of the tile, float4s 4 skq and 4 skq + 8 of its 16 k
     int arow = m0 + srow;
     arow = arow < M ? arow : M - 1;                           // (rows past the end: clamped loads, masked stores)
     const float* ap = A + (int64_t)arow * K + 4 * skq;
@@ -783,17 +785,30 @@ __global__ __launch_bounds__(256) void ce_gemm_f32(const float* __restrict__ A, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     const int r = lane & 31, kh = lane >> 5;
-    for (int k0 = 0; k0 < K; k0 += 8) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(ap + k0);
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + k0);
-        __syncthreads();                                      // the previous tile has been read
-        As[(4 * skq + 0) * CE_F32_LD + srow] = av.x; As[(4 * skq + 1) * CE_F32_LD + srow] = av.y;
-        As[(4 * skq + 2) * CE_F32_LD + srow] = av.z; As[(4 * skq + 3) * CE_F32_LD + srow] = av.w;
-        Ws[(4 * skq + 0) * CE_F32_LD + srow] = wv.x; Ws[(4 * skq + 1) * CE_F32_LD + srow] = wv.y;
-        Ws[(4 * skq + 2) * CE_F32_LD + srow] = wv.z; Ws[(4 * skq + 3) * CE_F32_LD + srow] = wv.w;
-        __syncthreads();
+    f32x4 av[2], wv[2];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {                      // k pairs: lanes < 32 hold k = 2 kk, lanes >= 32 k = 2 kk + 1
+    for (int h2 = 0; h2 < 2; ++h2) {
+        av[h2] = *reinterpret_cast<const f32x4*>(ap + 8 * h2);
+        wv[h2] = *reinterpret_cast<const f32x4*>(wp + 8 * h2);
+    }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        __syncthreads();                                      // the previous tile has been read
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int kb = (4 * skq + 8 * h2) * CE_F32_LD + srow;
+            As[kb] = av[h2].x; As[kb + CE_F32_LD] = av[h2].y; As[kb + 2 * CE_F32_LD] = av[h2].z; As[kb + 3 * CE_F32_LD] = av[h2].w;
+            Ws[kb] = wv[h2].x; Ws[kb + CE_F32_LD] = wv[h2].y; Ws[kb + 2 * CE_F32_LD] = wv[h2].z; Ws[kb + 3 * CE_F32_LD] = wv[h2].w;
+        }
+        __syncthreads();
+        if (k0 + 16 < K) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                av[h2] = *reinterpret_cast<const f32x4*>(ap + k0 + 16 + 8 * h2);
+                wv[h2] = *reinterpret_cast<const f32x4*>(wp + k0 + 16 + 8 * h2);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {                      // k pairs: lanes < 32 hold k = 2 kk, lanes >= 32 k = 2 kk + 1
             const int kr = (2 * kk + kh) * CE_F32_LD;
             const float a0 = As[kr + wm + r], a1 = As[kr + wm + 32 + r];
             const float b0 = Ws[kr + wn + r], b1 = Ws[kr + wn + 32 + r];
