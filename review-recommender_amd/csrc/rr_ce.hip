@@ -862,66 +862,89 @@ __global__ __launch_bounds__(256) void ce_add_ln_f32(const float* __restrict__ y
     }
 }
 
-// softmax(Q K^T / sqrt(32)) V of one (sequence, head), fp32: K and V of the head in LDS, one query per thread (its 32
-// dims and 32 outputs in registers), fp32 softmax with exact exp.
+// softmax(Q K^T / sqrt(32)) V of one (sequence, head) in fp32 on the fp32-input matrix instruction.  K (rows padded to 33
+// floats: the A operand below reads 32 consecutive keys at one dim) and V of the head sit in LDS as fp32; a wave owns tiles of
+// 32 queries.  Per 32-key tile:  S^T = K Q^T  (A = K: lane l = key l & 31, dim 2 s + (l >> 5); B = Q^T held in 16 registers
+// per lane for the whole query tile), so a lane holds ONE query's scores against 16 keys (C layout: register 4 g + i = key
+// 8 g + 4 h + i, h = l >> 5): the running maximum / sum of the online softmax are per-lane values plus one exchange with
+// lane ^ 32, and the probabilities are the B operand of  O^T += V^T P^T  as they sit (A = V^T: lane l = dim l & 31, key of
+// register t in its half) -- no lane movement, no LDS round trip.  exp is expf: fp32 rounding apart, the two-pass softmax.
+#define CE_F32_KLD 33
 __global__ __launch_bounds__(256) void ce_attention_f32(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
                                                         float* __restrict__ ctx, float scale) {
-    extern __shared__ float kv[];                             // K [S][32], V [S][32]
-    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x;
+    extern __shared__ float kv[];                             // K [Sp][33], V [Sp][32], Sp = S rounded up to 32
+    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    const int Sp = (S + 31) & ~31;
     float* Ks = kv;
-    float* Vs = kv + (size_t)S * CE_HD;
-    for (int i = tid; i < S * (CE_HD / 4); i += 256) {
-        const int j = i / (CE_HD / 4), c = i % (CE_HD / 4);
-        const float* row = qkv + (int64_t)(t0 + j) * (3 * CE_H) + head * CE_HD + 4 * c;
-        *reinterpret_cast<f32x4*>(Ks + j * CE_HD + 4 * c) = *reinterpret_cast<const f32x4*>(row + CE_H);
-        *reinterpret_cast<f32x4*>(Vs + j * CE_HD + 4 * c) = *reinterpret_cast<const f32x4*>(row + 2 * CE_H);
+    float* Vs = kv + (size_t)Sp * CE_F32_KLD;
+    for (int i = tid; i < Sp * (CE_HD / 4); i += 256) {
+        const int j = i / (CE_HD / 4), c4 = i % (CE_HD / 4);
+        f32x4 k4 = {0.f, 0.f, 0.f, 0.f}, v4 = {0.f, 0.f, 0.f, 0.f};       // rows past the sequence: zeros (their scores are masked)
+        if (j < S) {
+            const float* row = qkv + (int64_t)(t0 + j) * (3 * CE_H) + head * CE_HD + 4 * c4;
+            k4 = *reinterpret_cast<const f32x4*>(row + CE_H);
+            v4 = *reinterpret_cast<const f32x4*>(row + 2 * CE_H);
+        }
+        float* kd = Ks + j * CE_F32_KLD + 4 * c4;
+        kd[0] = k4.x; kd[1] = k4.y; kd[2] = k4.z; kd[3] = k4.w;
+        *reinterpret_cast<f32x4*>(Vs + j * CE_HD + 4 * c4) = v4;
     }
     __syncthreads();
-    for (int qi = tid; qi < S; qi += 256) {
-        float q[CE_HD], o[CE_HD];
-        const float* qp = qkv + (int64_t)(t0 + qi) * (3 * CE_H) + head * CE_HD;
+    const int c = lane & 31, h = lane >> 5;
+    for (int q0 = 32 * wave; q0 < S; q0 += 128) {
+        int qrow = q0 + c;
+        qrow = qrow < S ? qrow : S - 1;                       // (lanes past the sequence: a valid row, never stored)
+        const float* qp = qkv + (int64_t)(t0 + qrow) * (3 * CE_H) + head * CE_HD + h;
+        float qreg[16];
 #pragma unroll
-        for (int d = 0; d < CE_HD; ++d) { q[d] = qp[d]; o[d] = 0.f; }
-        // keys in chunks of 32: the chunk's scores once, ONE rescaling of the running sums per chunk (online softmax in
-        // fp32: exp(s - m) with the running maximum m; differs from the two-pass form by fp32 rounding only)
+        for (int st = 0; st < 16; ++st) qreg[st] = qp[2 * st];
+        f32x16r o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
         float mx = -INFINITY, l = 0.f;
-        for (int j0 = 0; j0 < S; j0 += 32) {
-            const int nj = S - j0 < 32 ? S - j0 : 32;
-            float sj[32];
+        for (int j0 = 0; j0 < Sp; j0 += 32) {
+            f32x16r sT;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sT[e] = 0.f;
+            const float* kp = Ks + (j0 + c) * CE_F32_KLD + h;
+#pragma unroll
+            for (int st = 0; st < 16; ++st) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * st], qreg[st], sT, 0, 0, 0);
             float cm = -INFINITY;
 #pragma unroll
-            for (int jj = 0; jj < 32; ++jj) {
-                float s = 0.f;
-                if (jj < nj) {
-#pragma unroll
-                    for (int d = 0; d < CE_HD; ++d) s = __builtin_fmaf(q[d], Ks[(j0 + jj) * CE_HD + d], s);
-                    s *= scale;
-                    cm = fmaxf(cm, s);
-                } else s = -INFINITY;
-                sj[jj] = s;
+            for (int e = 0; e < 16; ++e) {
+                const int key = j0 + 8 * (e >> 2) + 4 * h + (e & 3);
+                const float v = key < S ? sT[e] * scale : -INFINITY;
+                sT[e] = v;
+                cm = fmaxf(cm, v);
             }
-            if (cm > mx) {
-                const float c = expf(mx - cm);         // (first chunk: exp(-inf) = 0 on zero sums)
-                l *= c;
+            cm = fmaxf(cm, __shfl_xor(cm, 32, 64));           // the query's other 16 keys of this tile
+            if (cm > mx) {                                    // (per lane: a query's two lanes decide alike)
+                const float r = expf(mx - cm);                // first tile: exp(-inf) = 0 on zero sums
+                l *= r;
 #pragma unroll
-                for (int d = 0; d < CE_HD; ++d) o[d] *= c;
+                for (int e = 0; e < 16; ++e) o[e] *= r;
                 mx = cm;
             }
 #pragma unroll
-            for (int jj = 0; jj < 32; ++jj) {
-                if (jj < nj) {
-                    const float p = expf(sj[jj] - mx);
-                    l += p;
-#pragma unroll
-                    for (int d = 0; d < CE_HD; ++d) o[d] = __builtin_fmaf(p, Vs[(j0 + jj) * CE_HD + d], o[d]);
-                }
+            for (int e = 0; e < 16; ++e) {
+                const float pe = expf(sT[e] - mx);            // masked keys: exp(-inf) = 0
+                sT[e] = pe;
+                l += pe;
             }
-        }
-        const float inv = 1.0f / l;
-        float* op = ctx + (int64_t)(t0 + qi) * CE_H + head * CE_HD;
+            const float* vp = Vs + (j0 + 4 * h) * CE_HD + c;
 #pragma unroll
-        for (int d = 0; d < CE_HD; ++d) op[d] = o[d] * inv;
+            for (int e = 0; e < 16; ++e)                      // key of register e in this lane half: 8 (e >> 2) + 4 h + (e & 3)
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[(8 * (e >> 2) + (e & 3)) * CE_HD], sT[e], o, 0, 0, 0);
+        }
+        l += __shfl_xor(l, 32, 64);
+        if (q0 + c < S) {
+            const float inv = 1.0f / l;
+            float* op = ctx + (int64_t)(t0 + q0 + c) * CE_H + head * CE_HD + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)                       // register 4 g + i = dim 8 g + 4 h + i: 16 contiguous bytes per g
+                *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+        }
     }
 }
 
@@ -1140,7 +1163,7 @@ static int ce_set_attributes(int device) {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512)));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CE_FFN_BUF * 2));
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * CE_HD * 4));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * (CE_F32_KLD + CE_HD) * 4));
     done[device] = true;
     return RR_OK;
 }
@@ -1170,7 +1193,7 @@ static int ce_forward_f32(rr_ce* ce, const int32_t* d_token_ids, const int32_t* 
                        ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type, ce->eln_g, ce->eln_b,
                        ce->cfg.ln_eps, ce->h32, ce->hb);
     const unsigned mt = (unsigned)((T + 127) / 128), ln_blocks = (unsigned)((T + 3) / 4);
-    const size_t att_lds = (size_t)2 * max_len * CE_HD * 4;
+    const size_t att_lds = (size_t)((max_len + 31) & ~31) * (CE_F32_KLD + CE_HD) * 4;
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
         hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(3 * CE_H / 128, mt), dim3(256), 0, st, ce->h32, L.wqkv32, L.bqkv, T, 3 * CE_H, CE_H, ce->qkv32);
