@@ -1136,6 +1136,12 @@ __global__ __launch_bounds__(256) void rr_rescore_chain(
 #pragma unroll
         for (int i = 0; i < 6; ++i) qreg[i] = qv[16 * i + sub];
     }
+    f32x4 qpl[6];                                              // the query in the plane pre-scoring's lane order
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        qpl[2 * i] = (!A_BF16 && plane_rows) ? qv[2 * (sub + 16 * i)] : f32x4{0.f, 0.f, 0.f, 0.f};
+        qpl[2 * i + 1] = (!A_BF16 && plane_rows) ? qv[2 * (sub + 16 * i) + 1] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n; slot += gridDim.x * 4) {
         const int64_t m8 = mtiles[(int64_t)q * RR_X3_MCAP + slot];
         float mine = 0.f;
@@ -1162,18 +1168,23 @@ __global__ __launch_bounds__(256) void rr_rescore_chain(
             } else {
                 bool exact = true;
                 if (plane_rows) {
-                    // the plane row in the fp32 chain's own lane order: lane `sub` holds dims 4 (16 i + sub) .. + 3 of the
-                    // query (qreg[i]) and reads those four bf16 values (8 bytes) of the plane row
-                    const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(plane_rows + row * 48) + sub;
+                    // the plane row in 16-byte pieces (lane `sub`: units sub, sub + 16, sub + 32 = dims 8 (sub + 16 i) .. + 7,
+                    // the query's values for them in qpl): three loads of 1 KiB per wave instead of six of 512 B.  Only a
+                    // filter (within eps of the exact score in any summation order): the exact chain below decides.
+                    const u32x4* pp = plane_rows + row * 48 + sub;
                     float est = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        const unsigned long long x = pp[16 * i];
-                        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-                        est = __builtin_fmaf(__uint_as_float(lo << 16), qreg[i].x, est);
-                        est = __builtin_fmaf(__uint_as_float(lo & 0xFFFF0000u), qreg[i].y, est);
-                        est = __builtin_fmaf(__uint_as_float(hi << 16), qreg[i].z, est);
-                        est = __builtin_fmaf(__uint_as_float(hi & 0xFFFF0000u), qreg[i].w, est);
+                    for (int i = 0; i < 3; ++i) {
+                        const u32x4 x = pp[16 * i];
+                        const f32x4 q0 = qpl[2 * i], q1 = qpl[2 * i + 1];
+                        est = __builtin_fmaf(__uint_as_float(x.x << 16), q0.x, est);
+                        est = __builtin_fmaf(__uint_as_float(x.x & 0xFFFF0000u), q0.y, est);
+                        est = __builtin_fmaf(__uint_as_float(x.y << 16), q0.z, est);
+                        est = __builtin_fmaf(__uint_as_float(x.y & 0xFFFF0000u), q0.w, est);
+                        est = __builtin_fmaf(__uint_as_float(x.z << 16), q1.x, est);
+                        est = __builtin_fmaf(__uint_as_float(x.z & 0xFFFF0000u), q1.y, est);
+                        est = __builtin_fmaf(__uint_as_float(x.w << 16), q1.z, est);
+                        est = __builtin_fmaf(__uint_as_float(x.w & 0xFFFF0000u), q1.w, est);
                     }
                     est = rr_row16_sum(est);
                     exact = est >= pre_thr || !(est == est);          // (the 16 lanes of a row agree; NaN: let the exact chain decide)

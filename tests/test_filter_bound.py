@@ -70,6 +70,21 @@ def _fp32_chain(rows, q):
     return lanes[:, 0]
 
 
+def _plane_chain(rows, q):
+    """The plane pre-scoring of rr_rescore_chain: lane j of 16 takes the 16-byte units j, j + 16, j + 32 of the bf16 plane
+    row (8 elements each: dims 8 (j + 16 i) .. + 7), one fmaf chain over its 24 elements, pairwise sum of the 16 partials."""
+    n = rows.shape[0]
+    lanes = np.zeros((n, 16), dtype=np.float32)
+    r8 = rows.reshape(n, 3, 16, 8)
+    q8 = q.reshape(3, 16, 8)
+    for i in range(3):
+        for e in range(8):
+            lanes = (lanes.astype(np.float64) + r8[:, i, :, e].astype(np.float64) * q8[i, :, e].astype(np.float64)).astype(np.float32)
+    for step in (8, 4, 2, 1):
+        lanes = lanes + lanes[:, np.arange(16) ^ step]
+    return lanes[:, 0]
+
+
 @pytest.mark.parametrize("kind", ["unit", "scaled"])
 def test_plane_prescoring_of_rescored_rows_never_drops_a_pool_row(kind):
     """rr_rescore_chain scores a candidate row on its bf16 plane row first (sum a~_k q_k with the fp32 query) and runs
@@ -89,7 +104,7 @@ def test_plane_prescoring_of_rescored_rows_never_drops_a_pool_row(kind):
     s_scan = Vr @ qr                                          # what the filter scan estimates
     tau_est = np.sort(s_scan)[-pool]
     exact = _fp32_chain(V, q)
-    est = _fp32_chain(Vr.astype(np.float32), q)               # the plane row against the fp32 query
+    est = _plane_chain(Vr.astype(np.float32), q)              # the plane row against the fp32 query
     assert np.abs(est.astype(np.float64) - exact.astype(np.float64)).max() <= eps
     pre_thr = (tau_est - 1.02 * eps) - 1.01 * eps
     takes_chain = est >= pre_thr
