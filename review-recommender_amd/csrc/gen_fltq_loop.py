@@ -22,7 +22,8 @@ Hazards kept by construction (wait states = instructions in between):
 Usage: python gen_fltq_loop.py > rr_fltq_loop.inc   (build.py checks that the committed .inc is up to date)
        python gen_fltq_loop.py --abl 1,2,3,... > rr_fltq_loop_abl.inc   (debug harness only: timing ablations of the loop,
        selected by `if constexpr (ABL == n)`; bits: 1 no LDS-DMA pieces, 2 no epilogue instructions / stores, 4 no vmcnt wait +
-       barrier, 8 no A reads (stale operands), 64 pieces re-read the same M-tile (cache hits); 128 = nothing ablated)
+       barrier, 8 no A reads (stale operands), 64 pieces re-read the same M-tile (cache hits), 512 no epilogue instructions
+       in the restart bubble at the top of an M-tile (all of them in MFMA shadows); 128 = nothing ablated)
 """
 import sys
 
@@ -33,6 +34,8 @@ AD = 4                 # A operands (16 rows x 32 dims: four MFMAs each) request
 TILE_BYTES = 32 * 768  # one 32-row M-tile image
 PIECES = 6             # LDS-DMA pieces per wave and M-tile (four waves: 24 pieces of 8 rows x 128 B)
 HALF_BYTES = 16 * 768  # rows 16 .. 31 of an image sit this far behind rows 0 .. 15
+BUBBLE = 0             # epilogue instructions placed at the top of an M-tile, in front of its first MFMA (measured r03 with 22:
+                       # 1 816 -> 1 912 cycles per M-tile, +2 % wall -- the first A operand is back sooner than they issue; off)
 CAPS = (2, 1, 1, 0)    # filler instructions behind the MFMA of 16-query fragment n = 0 .. 3 of an operand (a 16-cycle MFMA
                        # leaves the wave 8 issue cycles; the next operand's ds_read + s_waitcnt stand behind fragment 3)
 
@@ -173,6 +176,14 @@ def gen_body(S, k):
     if ABL & 2:
         progs = [[], []]
     nxt = [0, 0]
+    # (experiment, BUBBLE > 0: epilogue instructions between the first A reads and the first MFMA of the M-tile)
+    for _ in range(0 if (ABL & 512) else BUBBLE):
+        # fragment 0 first; fragment 1 (last written by the previous body's LAST MFMA) only behind >= 18 issued instructions
+        t = 0 if (nxt[0] < len(progs[0]) and S.ok(progs[0][nxt[0]])) else 1
+        if t == 1 and (nxt[0] < 12 or nxt[1] >= len(progs[1]) or not S.ok(progs[1][nxt[1]])):
+            break
+        S.emit(progs[t][nxt[t]])
+        nxt[t] += 1
     start_gap = [2, 10]                             # first gap a fragment's epilogue may use
     dma_gaps = {4 * (4 * j + 3): j for j in range(PIECES)}          # behind the first MFMA of operands 3, 7, ... 23
     for idx in range(96):
