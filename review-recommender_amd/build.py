@@ -44,7 +44,7 @@ def _headers(debug: bool = False):
     return sorted(CSRC.glob("*.h")) + incs + [PKG_DIR.parent / "include" / "rr_hip.h"]
 
 
-FLTQ_ABLATIONS = "128,1,2,3,4,8,64,66"      # tools/fltq_ablate.py variants 3000 + n (rr_dense_flt.hip: RR_FLTQA_CASE)
+FLTQ_ABLATIONS = "128,1,2,3,4,8,64,66,1025,1026,1027,1028,1029,1030"      # tools/fltq_ablate.py variants 3000 + n (rr_dense_flt.hip: RR_FLTQA_CASE)
 
 
 def check_generated(debug: bool = False) -> None:

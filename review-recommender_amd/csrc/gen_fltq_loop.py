@@ -240,8 +240,13 @@ def gen_body(S, k):
 
 def emit_loop(abl=0):
     """The asm statement of the loop (a C++ block), as text; abl = ablation bits (0: the product's loop)."""
-    global ABL
+    global ABL, CAPS, AD
     ABL = abl
+    # 1024 + v: schedule variants for same-box A/Bs (nothing ablated: correct results)
+    CAPS, AD = {1025: ((1, 1, 1, 1), 4), 1026: ((2, 2, 0, 0), 4), 1027: ((2, 1, 1, 0), 6), 1028: ((2, 1, 1, 0), 3),
+                1029: ((3, 1, 0, 0), 4), 1030: ((2, 2, 0, 0), 6)}.get(abl, ((2, 1, 1, 0), 4))
+    if abl >= 1024:
+        ABL = 0
     S = Stream()
     S.raw("L_fltq_loop_%=:", 0)
     for k in range(4):
@@ -255,7 +260,7 @@ def emit_loop(abl=0):
     S.raw("s_nop 7", 8)
     out = []
     out.append("{")
-    out.append("    u32x4 tA0, tA1, tA2, tA3, tA4;")
+    out.append("    u32x4 " + ", ".join(f"tA{i}" for i in range(AD + 1)) + ";")
     out.append("    uint32_t " + ", ".join(f"tx{t}_{i}" for t in (0, 1) for i in range(10)) + ";")
     out.append("    uint64_t tc0_0, tc1_0;")
     out.append("    asm volatile(")

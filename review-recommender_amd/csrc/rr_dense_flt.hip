@@ -1788,7 +1788,7 @@ extern "C" int rr_debug_scan_flt(rr_index* ix, int32_t dbg, int32_t reps, float*
         // 3000 + bits: its generated timing ablations with the whole-loop cycle count (=> the shader clock of the launch)
 #define RR_FLTQA_CASE(b) case 3000 + (b): *out_ms = rr_debug_time_fltq_asm<(b)>(ix, st, reps); break;
         RR_FLTQA_CASE(0) RR_FLTQA_CASE(128) RR_FLTQA_CASE(1) RR_FLTQA_CASE(2) RR_FLTQA_CASE(3) RR_FLTQA_CASE(4) RR_FLTQA_CASE(8)
-        RR_FLTQA_CASE(64) RR_FLTQA_CASE(66)
+        RR_FLTQA_CASE(64) RR_FLTQA_CASE(66) RR_FLTQA_CASE(1025) RR_FLTQA_CASE(1026) RR_FLTQA_CASE(1027) RR_FLTQA_CASE(1028) RR_FLTQA_CASE(1029) RR_FLTQA_CASE(1030)
 #undef RR_FLTQA_CASE
         case 400:
             RR_REQUIRE(ix->shadow_valid, "no bf16 filter plane yet: run a batched search first");

@@ -22,5 +22,5 @@ print(f"asm loop vs C++ bodies: {cmp[0]} of {cmp[2]} tile words differ, {cmp[1]}
 only = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else [1000, 3000, 1000, 3000, 1002, 1003, 1000, 3000]
 for v in only:
     ms = C.c_float()
-    _lib.check(lib.rr_debug_scan_flt(ix.handle, v, 5, C.byref(ms)), "rr_debug_scan_flt")
+    _lib.check(lib.rr_debug_scan_flt(ix.handle, v, int(os.environ.get("RR_ABLATE_REPS", "5")), C.byref(ms)), "rr_debug_scan_flt")
     print(f"variant {v:3d}: {ms.value:.3f} ms  {n * 768 / ms.value / 1e6:.0f} GB/s", flush=True)
