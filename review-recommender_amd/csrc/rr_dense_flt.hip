@@ -77,10 +77,19 @@ __global__ __launch_bounds__(64) void rr_flt_pad_prep_queries(const float* __res
                                                               unsigned short* __restrict__ plane, float* __restrict__ eps, rr_flt_bounds B) {
     const int slot = blockIdx.x, lane = threadIdx.x;
     float ss = 0.f, sr = 0.f, sd = 0.f;
+    // (dim 384, the reference's encoders: the row as 96 sixteen-byte loads -- the queries may sit in pinned host memory, where
+    //  a wave instruction of 1 KiB crosses PCIe four times as well as one of 256 B; lane order of the sums is unchanged)
+    __shared__ float row[384];
+    const bool wide = dim == 384 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+    if (wide && slot < nq) {
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(src + (int64_t)slot * 384);
+        for (int u = lane; u < 96; u += 64) *reinterpret_cast<f32x4*>(row + 4 * u) = s4[u];
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int pos = lane + 64 * i;
-        const float x = (slot < nq && pos < dim) ? src[(int64_t)slot * dim + pos] : 0.f;
+        const float x = wide ? (slot < nq ? row[pos] : 0.f) : ((slot < nq && pos < dim) ? src[(int64_t)slot * dim + pos] : 0.f);
         padded[(int64_t)slot * 384 + pos] = x;
         const __bf16 r = (__bf16)x;                                // round to nearest even
         const float xr = (float)r, d = x - xr;
@@ -1389,7 +1398,9 @@ static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, 
     static const bool no_pre = getenv("RR_NO_RESCORE_PLANE") != nullptr;
     const u32x4* plane_rows = (!ROWS_BF16 && ix->shadow_valid && ix->d_shadow && !no_pre)
                                   ? reinterpret_cast<const u32x4*>(ix->d_shadow) : nullptr;
-    hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
+    // (four M-tiles per workgroup and pass; under a corpus-wide floor a shard opens ~pool / 8 M-tiles per query: a quarter of the
+    //  workgroups -- 24 k fewer empty ones to dispatch per call)
+    hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(floor ? 32 : 128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
                        X.mtiles, X.count, X.fb, X.sc, plane_rows, X.tau, X.eps);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st, floor != nullptr);
     RR_HIP_TRY(hipGetLastError());

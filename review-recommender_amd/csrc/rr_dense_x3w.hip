@@ -71,9 +71,10 @@ __global__ __launch_bounds__(((NQ2 == 2 && !(DBG & 32)) ? 512 : 256), 2) void rr
         sims += y * sims_slice; gmax += y * gmax_slice; smax += y * smax_slice;
     }
     if (STORE && fallback) {
-        int any = 0;
-        for (int i = 0; i < n_flags; ++i) any |= fallback[i];
-        if (!any) return;                                  // uniform: nobody needs the stored scores
+        // (n_flags <= 64: one flag per lane, one load; every wave of the workgroup sees the same answer)
+        const int li = threadIdx.x & 63;
+        const int mine = li < n_flags ? fallback[li] : 0;
+        if (!__any(mine)) return;                          // uniform: nobody needs the stored scores
     }
     constexpr int QN = 32 * NQ2;
     constexpr int ROWU = A_BF16 ? 48 : 96;            // 16-byte units per matrix row
