@@ -62,6 +62,7 @@ struct rr_index {
     float* d_flt_sigma = nullptr;    // [RR_FLT_MAXQ] per-query store threshold
     uint32_t* d_flt_prog = nullptr;  // [2][n_waves] progress words of the two-set scan launch (pairs of waves keep in step)
     uint32_t flt_seq = 0;            // launch counter of the two-set scan (epoch of the progress words)
+    bool scratch_small = false;      // no room for one score slice per 64 queries of a call: the fallback goes block by block
     bool flt_prep_fresh = false;     // rr_flt_pad_prep has written the planes / bounds of the queries in d_q (slots 0 ..): the next filter call skips its own preparation launch
     void* flt_pending = nullptr;     // rr_flt_pending: what a scan-only call (row shards, phase 1) left for its selection
     unsigned short* d_shadow = nullptr;

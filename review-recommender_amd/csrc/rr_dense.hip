@@ -1110,7 +1110,7 @@ __global__ void rr_l2norm_f32(float* __restrict__ mat, int64_t n_rows, int dim_p
 
 // ------------------------------------------------------------------ host side
 static int rr_ensure_scratch(rr_index* ix, int nq) {
-    if (ix->scratch_q >= nq) return RR_OK;
+    if (ix->scratch_q >= nq || (ix->scratch_small && ix->scratch_q >= RR_MFMA_MAXQ)) return RR_OK;
     const int64_t n_tiles = rr_round_up(ix->n_rows, 64) / 64;
     if (ix->d_sims) hipFree(ix->d_sims);
     if (ix->d_gmax) hipFree(ix->d_gmax);
@@ -1120,7 +1120,18 @@ static int rr_ensure_scratch(rr_index* ix, int nq) {
     ix->d_smax = nullptr;
     ix->scratch_q = 0;
     const size_t groups_cap = (size_t)RR_MAX_SCAN_WAVES;   // one group maximum per scan wave
-    RR_HIP_TRY(hipMalloc(&ix->d_sims, sizeof(float) * (size_t)nq * n_tiles * 64));
+    // (more than 64 score slots only serve the sliced fallback of a filter call: when there is no room for them -- a very
+    //  large index -- 64 slots do, and the fallback goes block by block: rr_dense_x3w_fallback_all)
+    static const bool force_small = getenv("RR_SCRATCH_SMALL") != nullptr;   // (tests: the block-by-block fallback on a small index)
+    if ((force_small && nq > RR_MFMA_MAXQ) ||
+        hipMalloc(&ix->d_sims, sizeof(float) * (size_t)nq * n_tiles * 64) != hipSuccess) {
+        (void)hipGetLastError();
+        ix->d_sims = nullptr;
+        if (nq <= RR_MFMA_MAXQ) { rr_set_error("rr_dense_topk: out of device memory for the score scratch"); return RR_E_NOMEM; }
+        nq = RR_MFMA_MAXQ;
+        RR_HIP_TRY(hipMalloc(&ix->d_sims, sizeof(float) * (size_t)nq * n_tiles * 64));
+        ix->scratch_small = true;
+    }
     // tile / group maxima: up to RR_FLT_MAXQ queries per launch (x4: per-M-tile maxima of the matrix-core scans)
     const size_t nm = nq >= RR_MFMA_MAXQ ? RR_FLT_MAXQ : nq;
     // (the filter scan uses 2 words per 64-row tile and query: two sets of them fit, + one line per scan wave behind them)

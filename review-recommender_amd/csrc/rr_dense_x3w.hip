@@ -517,8 +517,17 @@ int rr_dense_x3w_fallback_all(rr_index* ix, const float* d_q, int nq, int pool, 
                               const int32_t* flags, hipStream_t st) {
     const bool b = ix->dtype == RR_DTYPE_BF16;
     const int slices = (nq + RR_MFMA_MAXQ - 1) / RR_MFMA_MAXQ;
-    RR_REQUIRE(slices >= 1 && slices <= 4 && ix->scratch_q >= slices * RR_MFMA_MAXQ, "fallback scratch holds %d query slots, %d wanted",
-               ix->scratch_q, slices * RR_MFMA_MAXQ);
+    RR_REQUIRE(slices >= 1 && slices <= 4, "rr_dense_x3w_fallback_all: %d queries", nq);
+    if (ix->scratch_q < slices * RR_MFMA_MAXQ) {
+        // one score slice only (no room for more: rr_ensure_scratch): the blocks of 64 queries one after the other
+        for (int q0 = 0; q0 < nq; q0 += RR_MFMA_MAXQ) {
+            const int n = nq - q0 < RR_MFMA_MAXQ ? nq - q0 : RR_MFMA_MAXQ;
+            const int rc = rr_dense_chunk_x3w_fallback(ix, d_q + (int64_t)q0 * ix->dim_pad, n, pool, d_rows + (int64_t)q0 * pool,
+                                                       d_scores + (int64_t)q0 * pool, flags + q0, st);
+            if (rc != RR_OK) return rc;
+        }
+        return RR_OK;
+    }
     static int waves[2] = {0, 0};
     if (!waves[b]) waves[b] = b ? rr_resident_waves((const void*)rr_scan_x3w<2, true, true>, 512, ix->device)
                                 : rr_resident_waves((const void*)rr_scan_x3w<2, false, true>, 512, ix->device);

@@ -138,3 +138,33 @@ def test_exact_scan_switch_differs_only_inside_the_tie_band(tmp_path):
         for o in (d, x):
             assert np.all(np.diff(o["s64"][i]) < 4e-7), i
     print(f"RR_SCAN_EXACT: {swapped} of {BATCH * POOL} positions differ, all inside the 4e-7 band")
+
+
+FLAGGED_CHILD = r"""
+import sys, json, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+from review_recommender_amd import synth
+from review_recommender_amd.index import ProductIndex
+V = synth.unit_rows(200_000, 384, 91)
+V[::10] = V[3]                                   # 20000 copies of row 3: a query equal to it overflows its candidate list
+Q = synth.unit_rows(200, 384, 92)
+Q[[0, 70, 199]] = V[3]                           # flagged queries in three of the four 64-query blocks
+ix = ProductIndex(V)
+rows, sims = ix.dense_topk(Q, 150)
+assert rows[70].tolist() == sorted({3} | set(range(0, 1500, 10)))[:150]
+print("RESULT " + json.dumps([hashlib.sha256(rows.tobytes()).hexdigest(), hashlib.sha256(sims.tobytes()).hexdigest()]))
+""" % ROOT
+
+
+def test_one_slice_of_score_scratch_serves_the_flagged_queries_block_by_block():
+    """An index too large for one score slice per 64 queries of a call keeps ONE slice and sends the flagged queries
+    through the exact scan block by block (rr_ensure_scratch / rr_dense_x3w_fallback_all); RR_SCRATCH_SMALL=1 forces that
+    on a small index.  Same rows and scores, bit for bit, as the sliced two-launch fallback."""
+    got = []
+    for env in ({}, {"RR_SCRATCH_SMALL": "1"}):
+        p = subprocess.run([sys.executable, "-c", FLAGGED_CHILD], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got.append([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1])
+    assert got[0] == got[1]
