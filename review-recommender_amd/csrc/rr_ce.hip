@@ -25,6 +25,7 @@
 //   ce_head          pooler (tanh) + classifier on the [CLS] rows, fp32
 // GEMM tiles: 32x32x16 bf16 MFMA, K-step 64 through LDS rows padded to 144 B (conflict-free ds_read_b128),
 // next K tile prefetched global -> registers under the MFMAs of the current one.
+#include <cmath>
 #include <vector>
 
 #include "rr_common.h"
@@ -98,21 +99,33 @@ __global__ __launch_bounds__(256) void ce_embed_ln(const int32_t* __restrict__ t
 // Two values at a time on the packed fp32 pipe (v_pk_mul / v_pk_fma / v_pk_add: two lanes' worth per instruction):
 // the same formula; gelu(x) = x/2 * (x >= 0 ? 2 - q : q) with q = poly(t) t exp(-z^2) = 1 - erf(|x| / sqrt 2).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define CE_GELU_X 4.5f
+__device__ constexpr float CE_GELU_P[11] = {4.877777100e-01f, 7.139661163e-02f, -1.809151024e-01f, 2.453869879e-01f, -1.558733135e-01f,
+                                            -3.181198984e-02f, 1.249853820e-01f, -5.963810533e-02f, -2.130715176e-02f, 2.488414198e-02f,
+                                            -4.885168280e-03f};
+// bf16 path: no transcendental (a v_rcp + a v_exp per value are 32 of the ~54 vector-pipe cycles the formula above costs per
+// value, and in ce_ffn_fused that stretch was longer than the matrix work beside it).  Phi(x) - 1/2 is odd and flat beyond
+// |x| = 4.5 (1/2 - 3.4e-6): a degree-10 polynomial in t = 2 min(|x|, 4.5) / 4.5 - 1 (weighted least-squares Chebyshev fit,
+// tools/fit_gelu.py), sign restored; |gelu_poly - gelu| <= 1.6e-5 for every x (the output is rounded to bf16 next: 2^-9
+// relative).  The fp32 mode keeps the formula above (ce_gelu).  In three pieces so that ce_ffn_fused can spread a value's
+// work over several MFMA slots: t, the Horner steps, the finish.
+__device__ __forceinline__ f32x2_t ce_gelu_t(f32x2_t x) {
+    const f32x2_t a = {__builtin_fminf(__builtin_fabsf(x[0]), CE_GELU_X), __builtin_fminf(__builtin_fabsf(x[1]), CE_GELU_X)};
+    return __builtin_elementwise_fma(a, (f32x2_t){2.f / CE_GELU_X, 2.f / CE_GELU_X}, (f32x2_t){-1.f, -1.f});
+}
+template <int K_HI, int K_LO>      // Horner steps with coefficients K_HI ... K_LO (h = P[10] before step 9)
+__device__ __forceinline__ f32x2_t ce_gelu_horner(f32x2_t h, f32x2_t t) {
+#pragma unroll
+    for (int k = K_HI; k >= K_LO; --k) h = __builtin_elementwise_fma(h, t, (f32x2_t){CE_GELU_P[k], CE_GELU_P[k]});
+    return h;
+}
+__device__ __forceinline__ f32x2_t ce_gelu_finish(f32x2_t h, f32x2_t x) {
+    const f32x2_t hs = {__builtin_copysignf(h[0], x[0]), __builtin_copysignf(h[1], x[1])};
+    return x * (hs + (f32x2_t){0.5f, 0.5f});
+}
 __device__ __forceinline__ f32x2_t ce_gelu2(f32x2_t x) {
-    const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
-    const f32x2_t z = ax * 0.70710678118654752f;
-    const f32x2_t d = __builtin_elementwise_fma(z, (f32x2_t){0.3275911f, 0.3275911f}, (f32x2_t){1.f, 1.f});
-    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    f32x2_t poly = __builtin_elementwise_fma(t, (f32x2_t){1.061405429f, 1.061405429f}, (f32x2_t){-1.453152027f, -1.453152027f});
-    poly = __builtin_elementwise_fma(poly, t, (f32x2_t){1.421413741f, 1.421413741f});
-    poly = __builtin_elementwise_fma(poly, t, (f32x2_t){-0.284496736f, -0.284496736f});
-    poly = __builtin_elementwise_fma(poly, t, (f32x2_t){0.254829592f, 0.254829592f});
-    const f32x2_t a = (z * z) * -1.4426950408889634f;
-    const f32x2_t e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-    const f32x2_t q = (poly * t) * e;
-    const f32x2_t two_q = (f32x2_t){2.f, 2.f} - q;
-    const f32x2_t r = {x[0] < 0.f ? q[0] : two_q[0], x[1] < 0.f ? q[1] : two_q[1]};
-    return (x * 0.5f) * r;
+    const f32x2_t t = ce_gelu_t(x);
+    return ce_gelu_finish(ce_gelu_horner<9, 0>((f32x2_t){CE_GELU_P[10], CE_GELU_P[10]}, t), x);
 }
 __device__ __forceinline__ float ce_gelu(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
@@ -374,17 +387,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
 #define CE_W1_LD (CE_H + 8)     // LDS row of a W1 chunk: 384 bf16 + 16 B pad
 #define CE_W2_LD (CE_FFN_CH + 8)    // LDS row of a W2 chunk: 32 bf16 + 16 B pad
 #define CE_FFN_BUF (CE_FFN_CH * CE_W1_LD + CE_H * CE_W2_LD)     // bf16 elements per chunk buffer
+#define CE_GELU_N 512           // intervals of the fused FFN's Phi table over [-CE_GELU_R, CE_GELU_R]
+#define CE_GELU_R 4.5f
+#define CE_FFN_LDS (2 * CE_FFN_BUF * 2 + CE_FFN * 4 + 3 * CE_H * 4 + CE_GELU_N * 8)   // two chunk buffers + b1 + (b2, ln_g, ln_b) + the Phi table
 
 // DEPTH: A fragments in flight.  STAGGER rotates the chunk order per workgroup (it spreads the L2 lines the CUs ask for at
 // one time, but makes a token's rounding depend on where it sits in the batch): measured r02 at 256 x 512 tokens, whole
 // forward: <4, false> 6.26 ms, <8, false> 6.38 ms, <4, true> 6.38 ms -- neither LDS depth nor L2 hot-spotting is what
 // bounds the kernel (a single wave per SIMD issues its VALU, LDS and MFMA work in order); only <4, false> is built.
+#ifdef RR_DEBUG_HARNESS
+// in-kernel phase clocks of ce_ffn_fused (tools/k5_stamps.py): [wave 0 of workgroups 0 and 600][8] cycle sums
+__device__ unsigned long long ce_dbg_ffn[2][10];
+#define CE_STAMP(slot) do { const unsigned long long t_ = clock64(); dbg_t[slot] += t_ - dbg_last; dbg_last = t_; } while (0)
+#else
+#define CE_STAMP(slot) do { } while (0)
+#endif
+
 template <int DEPTH, bool STAGGER>
 __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     unsigned short* __restrict__ hb, float* __restrict__ h32, int M,
     const unsigned short* __restrict__ W1, const float* __restrict__ b1,       // [1536][384], [1536]
     const unsigned short* __restrict__ W2p, const float* __restrict__ b2,      // [384][1536] columns permuted, [384]
-    const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps) {
+    const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
+    const float* __restrict__ gelu_tab) {                                       // [CE_GELU_N][2]: ce_gelu_table
     extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
     unsigned short* wbuf = reinterpret_cast<unsigned short*>(ce_smem);          // [2][CE_FFN_BUF]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -406,8 +431,11 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
 
     // chunk staging: a W1 chunk (rows j0 .. j0+31: 32 x 768 B) and a W2p chunk (columns j0 .. j0+31 of all 384 rows:
-    // 384 x 64 B) are 1536 pieces of 16 B each = 6 per thread; ONE set of six staging registers serves both in turn
-    u32x4 pw[6];
+    // 384 x 64 B) are 1536 pieces of 16 B each = 6 per thread, each kind with its own six staging registers: both loads
+    // are issued a whole chunk (>= 1536 matrix-pipe cycles) before their LDS stores, and NO other vector-memory load sits
+    // between a load and its store's wait (vmcnt retires in order: the b1 loads this loop used to issue per chunk made
+    // their first use wait for the weight prefetch issued just before them -- b1 now comes from LDS)
+    u32x4 pw[6], pw2[6];
     auto load_w1 = [&](int ch) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -419,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int id = tid + 256 * i;
-            pw[i] = *reinterpret_cast<const u32x4*>(W2p + (int64_t)(id >> 2) * CE_FFN + ch * CE_FFN_CH + (id & 3) * 8);
+            pw2[i] = *reinterpret_cast<const u32x4*>(W2p + (int64_t)(id >> 2) * CE_FFN + ch * CE_FFN_CH + (id & 3) * 8);
         }
     };
     auto w1_of = [&](int k) { return wbuf + (k & 1) * CE_FFN_BUF; };                          // LDS home of W1 chunk k
@@ -435,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int id = tid + 256 * i;
-            *reinterpret_cast<u32x4*>(buf + (id >> 2) * CE_W2_LD + (id & 3) * 8) = pw[i];
+            *reinterpret_cast<u32x4*>(buf + (id >> 2) * CE_W2_LD + (id & 3) * 8) = pw2[i];
         }
     };
     auto lds_barrier = [&]() {
@@ -444,6 +472,10 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         asm volatile("" ::: "memory");
     };
 
+#ifdef RR_DEBUG_HARNESS
+    unsigned long long dbg_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dbg_last = clock64();
+    const unsigned long long dbg_w0 = wall_clock64();
+#endif
     constexpr int NCH = CE_FFN / CE_FFN_CH;          // 48 chunks
     // DEPTH A fragments are in flight ahead of their MFMA: one wave per SIMD, so the LDS latency (~100+ cycles against
     // 32 per MFMA) is hidden by depth
@@ -453,13 +485,32 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     // (vector pipe: one v_rcp + one v_exp per value, the longest VALU stretch of the kernel) is computed -- they are
     // independent; only then does the second product of chunk ch consume the GELU's output.  With one wave per SIMD
     // nothing else would fill the matrix pipe during the GELU.
+    float* b1s = reinterpret_cast<float*>(wbuf + 2 * CE_FFN_BUF);               // [1536] the first bias, read per chunk
+    float* eps_ = b1s + CE_FFN;                                                 // [3][384] b2, ln_g, ln_b for the epilogue
+    for (int i = tid; i < CE_FFN / 4; i += 256) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(b1)[i];
+    float* gtab = eps_ + 3 * CE_H;                                              // [CE_GELU_N][2] Phi(x_i), Phi(x_i+1) - Phi(x_i)
+    for (int i = tid; i < CE_GELU_N / 2; i += 256) reinterpret_cast<f32x4*>(gtab)[i] = reinterpret_cast<const f32x4*>(gelu_tab)[i];
+    for (int i = tid; i < 3 * CE_H / 4; i += 256) {
+        const float* src = i < CE_H / 4 ? b2 : i < 2 * CE_H / 4 ? ln_g : ln_b;
+        reinterpret_cast<f32x4*>(eps_)[i] = reinterpret_cast<const f32x4*>(src)[i % (CE_H / 4)];
+    }
     load_w1(chunk_of(0)); store_w1(w1_of(0));
     load_w2(chunk_of(0)); store_w2(w2_of(0));
     load_w1(chunk_of(1)); store_w1(w1_of(1));
     lds_barrier();
-    f32x16 xc;                                       // raw X^T of the current chunk (before bias / GELU)
+    // register e of lane half hh is feature (e & 3) + 8 (e >> 2) + 4 hh of the chunk: the accumulator of a first product
+    // STARTS from the chunk's bias (four 16-byte LDS reads straight into the C operand: no vector add per value)
+    auto bias_of = [&](int k) {
+        f32x16 v;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) xc[e] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(b1s + chunk_of(k) * CE_FFN_CH + 8 * g + 4 * hh);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * g + r] = q[r];
+        }
+        return v;
+    };
+    f32x16 xc = bias_of(0);                          // X^T + b1 of the current chunk (before the GELU)
     {
         const unsigned short* ap = w1_of(0) + c * CE_W1_LD + 8 * hh;
         bf16x8 af[DEPTH];
@@ -474,41 +525,70 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     }
     lds_barrier();                                                         // every wave is done with W1 chunk 0: its home is reused below
     load_w1(chunk_of(2));                                                  // stored by iteration 0
+    CE_STAMP(0);                                                           // prologue
     for (int ch = 0; ch < NCH; ++ch) {
         const bool more = ch + 1 < NCH;
-        // register e of lane half hh is feature (e & 3) + 8 (e >> 2) + 4 hh of the chunk
-        f32x4 bv[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(b1 + chunk_of(ch) * CE_FFN_CH + 8 * g + 4 * hh);
-        bf16x8 xb[2];
-        auto gelu_pair = [&](int k) {                                      // values 2k, 2k + 1 of xc -> xb
-            const int e = 2 * k;
-            const f32x2_t v = ce_gelu2((f32x2_t){xc[e] + bv[e >> 2][e & 3], xc[e + 1] + bv[e >> 2][(e & 3) + 1]});
-            xb[e >> 3][e & 7] = (__bf16)v[0];
-            xb[e >> 3][(e & 7) + 1] = (__bf16)v[1];
+        if (more) load_w2(chunk_of(ch + 1));                               // stored after the second product below
+        u32x4 xbw[2];                                                      // GELU(X^T) as bf16 pairs: the B operand of the second product
+        // GELU(x) = x Phi(x), Phi by linear interpolation in a 512-interval table over [-4.5, 4.5] in LDS (ce_gelu_table;
+        // |error| <= 1e-5 on Phi, the output is rounded to bf16 next): 7 vector instructions + one 8-byte LDS gather per
+        // value, where the erf formula took ~20 and a v_rcp + v_exp.  Why it matters: one wave per SIMD issues in order,
+        // and the probe (tools/probes/mfma_valu_probe.hip) says a 32x32x16 MFMA hides ~5 four-cycle vector instructions --
+        // beyond that every further one adds its 4 cycles to the slot.  So the 16 values of a chunk are spread over the 24
+        // MFMA slots of the product beside them at <= 6 instructions per slot: look-up of value 2k in slot 3k, of 2k + 1 in
+        // slot 3k + 1, finish of pair k - 1 (its gathers are four slots old) in slot 3k + 2.  The empty asm statements pin
+        // each piece to its slot (the compiler otherwise sinks all of it below the MFMA loop, next to its use).
+        float gx[2][2], gf[2][2];
+        f32x2_t gt[2][2];
+        auto gelu_lookup = [&](int e) {                                    // value e of xc: interval, fraction, gather
+            const int k = e >> 1, i = e & 1;
+            float x = xc[e];
+            float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(x, CE_GELU_N / (2.f * CE_GELU_R), CE_GELU_N / 2.f), 0.f, 511.99997f);
+            unsigned int off = (unsigned int)t * 8u;
+            float f = __builtin_amdgcn_fractf(t);
+            asm volatile("" : "+v"(x), "+v"(f), "+v"(off));
+            gx[k & 1][i] = x;
+            gf[k & 1][i] = f;
+            gt[k & 1][i] = *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const unsigned char*>(gtab) + off);
         };
-        f32x16 xn;                                                         // X^T of chunk ch + 1
-#pragma unroll
-        for (int e = 0; e < 16; ++e) xn[e] = 0.f;
+        auto gelu_finish = [&](int k) {                                    // pair k -> xbw
+            const float y0 = gx[k & 1][0] * __builtin_fmaf(gf[k & 1][0], gt[k & 1][0][1], gt[k & 1][0][0]);
+            const float y1 = gx[k & 1][1] * __builtin_fmaf(gf[k & 1][1], gt[k & 1][1][1], gt[k & 1][1][0]);
+            unsigned int pk = __builtin_bit_cast(unsigned int, (bf16x2_t){(__bf16)y0, (__bf16)y1});
+            asm volatile("" : "+v"(pk));
+            xbw[k >> 2][k & 3] = pk;
+        };
+        auto gelu_slot = [&](int s) {
+            const int k = s / 3;
+            if (s % 3 == 0) gelu_lookup(2 * k);
+            else if (s % 3 == 1) gelu_lookup(2 * k + 1);
+            else if (k >= 1) gelu_finish(k - 1);
+        };
+        f32x16 xn = bias_of(more ? ch + 1 : ch);                           // X^T + b1 of chunk ch + 1
         if (more) {
             // ---- X^T(ch + 1) = W1 chunk . h^T on the matrix pipe, GELU(ch) on the vector pipe, interleaved
             const unsigned short* ap = w1_of(ch + 1) + c * CE_W1_LD + 8 * hh;
             bf16x8 af[DEPTH];
 #pragma unroll
             for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + 16 * i);
+            CE_STAMP(1);                                                   // top of the iteration (W2 loads, bias, first A fragments)
 #pragma unroll
             for (int s = 0; s < 24; ++s) {
                 xn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], xn, 0, 0, 0);
                 if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
-                if (s % 3 == 0) gelu_pair(s / 3);                           // 8 pairs over the 24 MFMA slots
+                gelu_slot(s);
                 __builtin_amdgcn_sched_barrier(0);
+                if (s == 11) CE_STAMP(2);                                  // slots 0 .. 11
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) gelu_pair(k);
+            for (int s = 0; s < 24; ++s) gelu_slot(s);
         }
+        gelu_finish(7);
+        CE_STAMP(3);                                                       // slots 12 .. 23 of the first product + GELU
         if (ch + 2 < NCH) store_w1(w1_of(ch + 2));                         // (its home held W1 chunk ch, last read a barrier ago)
-        if (more) load_w2(chunk_of(ch + 1));
+        if (ch + 3 < NCH) load_w1(chunk_of(ch + 3));                       // stored by the next iteration, here
+        CE_STAMP(4);                                                       // W1 staging
         // ---- out^T += W2 chunk . X^T(ch)
         {
             const unsigned short* ap = w2_of(ch) + c * CE_W2_LD + 8 * hh;
@@ -518,14 +598,16 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
             for (int i = 0; i < DEPTH; ++i) af[i] = frag(i);
 #pragma unroll
             for (int i = 0; i < 24; ++i) {                                  // i = 2 nb + s2
-                acc[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i % DEPTH], xb[i & 1], acc[i >> 1], 0, 0, 0);
+                acc[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i % DEPTH], __builtin_bit_cast(bf16x8, xbw[i & 1]), acc[i >> 1], 0, 0, 0);
                 if (i + DEPTH < 24) af[i % DEPTH] = frag(i + DEPTH);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        CE_STAMP(5);                                                       // second product
         if (more) store_w2(w2_of(ch + 1));                                 // (its home held W2 chunk ch - 1)
-        if (ch + 3 < NCH) load_w1(chunk_of(ch + 3));                                 // in flight over the barrier; stored next iteration
+        CE_STAMP(6);                                                       // W2 staging
         lds_barrier();
+        CE_STAMP(7);                                                       // barrier
         xc = xn;
     }
 
@@ -536,7 +618,7 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = nb * 32 + 8 * g + 4 * hh;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + n);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(eps_ + n);            // (LDS: two addresses per wave-instruction)
             const f32x4 rv = *reinterpret_cast<const f32x4*>(h32 + tok * CE_H + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -560,8 +642,8 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nb * 32 + 8 * g + 4 * hh;
-                const f32x4 gv = *reinterpret_cast<const f32x4*>(ln_g + n);
-                const f32x4 be = *reinterpret_cast<const f32x4*>(ln_b + n);
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(eps_ + CE_H + n);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(eps_ + 2 * CE_H + n);
                 f32x4 y;
                 bf16x4 yb;
 #pragma unroll
@@ -573,6 +655,13 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
                 *reinterpret_cast<bf16x4*>(hb + tok * CE_H + n) = yb;
             }
     }
+#ifdef RR_DEBUG_HARNESS
+    CE_STAMP(8);                                                           // bias + residual + LayerNorm + stores
+    if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 600)) {
+        dbg_t[9] = wall_clock64() - dbg_w0;
+        for (int i = 0; i < 10; ++i) ce_dbg_ffn[blockIdx.x ? 1 : 0][i] = dbg_t[i];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ attention: one workgroup per (sequence, head)
@@ -963,6 +1052,7 @@ struct rr_ce {
     float *word = nullptr, *pos = nullptr, *type = nullptr, *eln_g = nullptr, *eln_b = nullptr;
     rr_ce_layer* layers = nullptr;
     float *wp = nullptr, *bp = nullptr, *wc = nullptr, *bc = nullptr;
+    float* gelu_tab = nullptr;       // ce_gelu_table: the fused FFN's Phi table
     // activation scratch for `cap` tokens
     int64_t cap = 0;
     float* h32 = nullptr;
@@ -978,6 +1068,18 @@ struct rr_ce {
     bool timed = false;
     std::mutex mu;
 };
+
+// Phi(x) = (1 + erf(x / sqrt 2)) / 2 at the CE_GELU_N + 1 knots of [-CE_GELU_R, CE_GELU_R], as (value, step to the next knot)
+// pairs: ce_ffn_fused interpolates linearly (max error h^2 / 8 max|Phi''| = 9.4e-6) and clamps outside (Phi(-4.5) = 3.4e-6)
+static void ce_gelu_table(float* tab) {
+    const double h = 2.0 * CE_GELU_R / CE_GELU_N;
+    for (int i = 0; i < CE_GELU_N; ++i) {
+        const double a = 0.5 * (1.0 + std::erf((-CE_GELU_R + i * h) * 0.70710678118654752440));
+        const double b = 0.5 * (1.0 + std::erf((-CE_GELU_R + (i + 1) * h) * 0.70710678118654752440));
+        tab[2 * i] = (float)a;
+        tab[2 * i + 1] = (float)(b - a);
+    }
+}
 
 static int ce_upload_f32(float** dst, const float* src, size_t n) {
     *dst = nullptr;
@@ -1014,7 +1116,7 @@ extern "C" int rr_ce_destroy(rr_ce* ce) {
             hipFree(L.wqkv32); hipFree(L.wo32); hipFree(L.w1_32); hipFree(L.w2_32);
         }
     delete[] ce->layers;
-    hipFree(ce->wp); hipFree(ce->bp); hipFree(ce->wc); hipFree(ce->bc);
+    hipFree(ce->wp); hipFree(ce->bp); hipFree(ce->wc); hipFree(ce->bc); hipFree(ce->gelu_tab);
     hipFree(ce->h32); hipFree(ce->hb); hipFree(ce->qkv); hipFree(ce->ctx); hipFree(ce->inter);
     hipFree(ce->h32c); hipFree(ce->hbc); hipFree(ce->ctxc); hipFree(ce->interc);
     hipFree(ce->qkv32); hipFree(ce->y32); hipFree(ce->inter32);
@@ -1104,6 +1206,11 @@ extern "C" int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float
         f32(&ce->wp, p[0], H * H); f32(&ce->bp, p[1], H);
         f32(&ce->wc, p[2], (size_t)cfg->n_labels * H); f32(&ce->bc, p[3], (size_t)cfg->n_labels);
     }
+    if (!rc) {
+        std::vector<float> tab(2 * CE_GELU_N);
+        ce_gelu_table(tab.data());
+        f32(&ce->gelu_tab, tab.data(), tab.size());
+    }
     if (!rc && (hipEventCreate(&ce->ev0) != hipSuccess || hipEventCreate(&ce->ev1) != hipSuccess)) rc = RR_E_HIP;
     if (rc) { rr_ce_destroy(ce); return rc; }
     *out = ce;
@@ -1162,7 +1269,10 @@ static int ce_set_attributes(int device) {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512)));
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CE_FFN_BUF * 2));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
+#ifdef RR_DEBUG_HARNESS
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
+#endif
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * (CE_F32_KLD + CE_HD) * 4));
     done[device] = true;
     return RR_OK;
@@ -1250,7 +1360,7 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
                        ce->cfg.ln_eps, ce->h32, ce->hb);
     const size_t ldsB = (size_t)(128 + 384) * CE_LDK * 2;
     const size_t ldsP = 8 * 64 * (96 + 8) * 2;          // plain epilogues stage eight 64 x 96 sub-tiles (> the K-tile buffers)
-    const size_t ldsF = (size_t)2 * CE_FFN_BUF * 2;     // fused FFN: two chunk buffers
+    const size_t ldsF = (size_t)CE_FFN_LDS;     // fused FFN: two chunk buffers + biases / LayerNorm rows + the Phi table
     static const bool unfused = getenv("RR_CE_UNFUSED") != nullptr;   // A/B: FFN as two GEMM launches
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
@@ -1276,8 +1386,14 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
                            CE_H, rb, r32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
         if (!unfused) {
             const dim3 fg((unsigned)((Mr + CE_FFN_TOK - 1) / CE_FFN_TOK));
+#ifdef RR_DEBUG_HARNESS
+            static const bool depth8 = getenv("RR_CE_FFN_DEPTH8") != nullptr;      // (tools/k5_stamps.py: A fragments 8 slots ahead)
+            if (depth8) hipLaunchKernelGGL((ce_ffn_fused<8, false>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
+                                           L.ln2_b, ce->cfg.ln_eps, ce->gelu_tab);
+            else
+#endif
             hipLaunchKernelGGL((ce_ffn_fused<4, false>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
-                               L.ln2_b, ce->cfg.ln_eps);
+                               L.ln2_b, ce->cfg.ln_eps, ce->gelu_tab);
         } else {
             hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(Mr, 128, CE_FFN / 384)), dim3(512), ldsP, st, rb, L.w1, L.b1, Mr,
                                CE_FFN, CE_H, rint, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
@@ -1305,3 +1421,13 @@ extern "C" int rr_ce_last_forward_ms(rr_ce* ce, float* out_ms) {
     RR_HIP_TRY(hipEventElapsedTime(out_ms, ce->ev0, ce->ev1));
     return RR_OK;
 }
+
+#ifdef RR_DEBUG_HARNESS
+// tools/k5_stamps.py: phase clocks of the LAST ce_ffn_fused launch (wave 0 of workgroups 0 and 600): per workgroup
+// [prologue, iteration top, slots 0-11, slots 12-23, W1 staging, product 2, W2 staging, barrier, epilogue] shader cycles + wall_clock64 ticks (100 MHz)
+extern "C" int rr_debug_ce_ffn_stamps(unsigned long long* out20) {
+    RR_HIP_TRY(hipDeviceSynchronize());
+    RR_HIP_TRY(hipMemcpyFromSymbol(out20, HIP_SYMBOL(ce_dbg_ffn), sizeof(unsigned long long) * 20));
+    return RR_OK;
+}
+#endif

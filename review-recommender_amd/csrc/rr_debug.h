@@ -13,5 +13,7 @@ int rr_debug_scan_x3w(rr_index* ix, int32_t variant, int32_t reps, float* out_ms
 int rr_debug_scan_flt(rr_index* ix, int32_t variant, int32_t reps, float* out_ms);
 // the hand-scheduled loop of rr_scan_fltq against its C++ bodies, tile word by tile word (out: 7 values, see the definition)
 int rr_debug_fltq_compare(rr_index* ix, int64_t* out);
+// tools/k5_stamps.py: in-kernel phase clocks of the last ce_ffn_fused launch (rr_ce.hip)
+int rr_debug_ce_ffn_stamps(unsigned long long* out20);
 }
 #endif
