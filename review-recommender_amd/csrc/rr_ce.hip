@@ -26,6 +26,7 @@
 // GEMM tiles: 32x32x16 bf16 MFMA, K-step 64 through LDS rows padded to 144 B (conflict-free ds_read_b128),
 // next K tile prefetched global -> registers under the MFMAs of the current one.
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "rr_common.h"
@@ -424,11 +425,18 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 #pragma unroll
     for (int s = 0; s < 24; ++s) hf[s] = *reinterpret_cast<const bf16x8*>(hb + tok * CE_H + 16 * s + 8 * hh);
 
+    // out^T accumulates ON TOP of the token's residual row: its 48 loads are in flight under the staging of the first chunks
+    // instead of standing, all workgroups at once, between the last MFMA and the LayerNorm (r03 in-kernel clocks: the
+    // epilogue was 42 .. 66 thousand cycles of a workgroup's 250 thousand)
     f32x16 acc[12];
 #pragma unroll
     for (int nb = 0; nb < 12; ++nb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(h32 + tok * CE_H + nb * 32 + 8 * g + 4 * hh);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[nb][4 * g + r] = rv[r];
+        }
 
     // chunk staging: a W1 chunk (rows j0 .. j0+31: 32 x 768 B) and a W2p chunk (columns j0 .. j0+31 of all 384 rows:
     // 384 x 64 B) are 1536 pieces of 16 B each = 6 per thread, each kind with its own six staging registers: both loads
@@ -481,10 +489,6 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     // 32 per MFMA) is hidden by depth
     const int rot = STAGGER ? (int)((blockIdx.x * 7u) % NCH) : 0;          // (experiment: spreads the L2 lines the CUs ask for)
     auto chunk_of = [&](int k) { return STAGGER ? (k + rot) % NCH : k; };
-    // Software pipeline over the chunks: the first product of chunk ch + 1 (matrix pipe) runs while the GELU of chunk ch
-    // (vector pipe: one v_rcp + one v_exp per value, the longest VALU stretch of the kernel) is computed -- they are
-    // independent; only then does the second product of chunk ch consume the GELU's output.  With one wave per SIMD
-    // nothing else would fill the matrix pipe during the GELU.
     float* b1s = reinterpret_cast<float*>(wbuf + 2 * CE_FFN_BUF);               // [1536] the first bias, read per chunk
     float* eps_ = b1s + CE_FFN;                                                 // [3][384] b2, ln_g, ln_b for the epilogue
     for (int i = tid; i < CE_FFN / 4; i += 256) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(b1)[i];
@@ -495,7 +499,6 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         reinterpret_cast<f32x4*>(eps_)[i] = reinterpret_cast<const f32x4*>(src)[i % (CE_H / 4)];
     }
     load_w1(chunk_of(0)); store_w1(w1_of(0));
-    load_w2(chunk_of(0)); store_w2(w2_of(0));
     load_w1(chunk_of(1)); store_w1(w1_of(1));
     lds_barrier();
     // register e of lane half hh is feature (e & 3) + 8 (e >> 2) + 4 hh of the chunk: the accumulator of a first product
@@ -525,93 +528,107 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     }
     lds_barrier();                                                         // every wave is done with W1 chunk 0: its home is reused below
     load_w1(chunk_of(2));                                                  // stored by iteration 0
+    load_w2(chunk_of(0));                                                  // stored by iteration 0
     CE_STAMP(0);                                                           // prologue
-    for (int ch = 0; ch < NCH; ++ch) {
-        const bool more = ch + 1 < NCH;
-        if (more) load_w2(chunk_of(ch + 1));                               // stored after the second product below
-        u32x4 xbw[2];                                                      // GELU(X^T) as bf16 pairs: the B operand of the second product
-        // GELU(x) = x Phi(x), Phi by linear interpolation in a 512-interval table over [-4.5, 4.5] in LDS (ce_gelu_table;
-        // |error| <= 1e-5 on Phi, the output is rounded to bf16 next): 7 vector instructions + one 8-byte LDS gather per
-        // value, where the erf formula took ~20 and a v_rcp + v_exp.  Why it matters: one wave per SIMD issues in order,
-        // and the probe (tools/probes/mfma_valu_probe.hip) says a 32x32x16 MFMA hides ~5 four-cycle vector instructions --
-        // beyond that every further one adds its 4 cycles to the slot.  So the 16 values of a chunk are spread over the 24
-        // MFMA slots of the product beside them at <= 6 instructions per slot: look-up of value 2k in slot 3k, of 2k + 1 in
-        // slot 3k + 1, finish of pair k - 1 (its gathers are four slots old) in slot 3k + 2.  The empty asm statements pin
-        // each piece to its slot (the compiler otherwise sinks all of it below the MFMA loop, next to its use).
-        float gx[2][2], gf[2][2];
-        f32x2_t gt[2][2];
-        auto gelu_lookup = [&](int e) {                                    // value e of xc: interval, fraction, gather
-            const int k = e >> 1, i = e & 1;
-            float x = xc[e];
-            float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(x, CE_GELU_N / (2.f * CE_GELU_R), CE_GELU_N / 2.f), 0.f, 511.99997f);
-            unsigned int off = (unsigned int)t * 8u;
-            float f = __builtin_amdgcn_fractf(t);
-            asm volatile("" : "+v"(x), "+v"(f), "+v"(off));
-            gx[k & 1][i] = x;
-            gf[k & 1][i] = f;
-            gt[k & 1][i] = *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const unsigned char*>(gtab) + off);
-        };
-        auto gelu_finish = [&](int k) {                                    // pair k -> xbw
-            const float y0 = gx[k & 1][0] * __builtin_fmaf(gf[k & 1][0], gt[k & 1][0][1], gt[k & 1][0][0]);
-            const float y1 = gx[k & 1][1] * __builtin_fmaf(gf[k & 1][1], gt[k & 1][1][1], gt[k & 1][1][0]);
-            unsigned int pk = __builtin_bit_cast(unsigned int, (bf16x2_t){(__bf16)y0, (__bf16)y1});
-            asm volatile("" : "+v"(pk));
-            xbw[k >> 2][k & 3] = pk;
-        };
-        auto gelu_slot = [&](int s) {
-            const int k = s / 3;
-            if (s % 3 == 0) gelu_lookup(2 * k);
-            else if (s % 3 == 1) gelu_lookup(2 * k + 1);
-            else if (k >= 1) gelu_finish(k - 1);
-        };
-        f32x16 xn = bias_of(more ? ch + 1 : ch);                           // X^T + b1 of chunk ch + 1
-        if (more) {
-            // ---- X^T(ch + 1) = W1 chunk . h^T on the matrix pipe, GELU(ch) on the vector pipe, interleaved
-            const unsigned short* ap = w1_of(ch + 1) + c * CE_W1_LD + 8 * hh;
-            bf16x8 af[DEPTH];
-#pragma unroll
-            for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + 16 * i);
-            CE_STAMP(1);                                                   // top of the iteration (W2 loads, bias, first A fragments)
-#pragma unroll
-            for (int s = 0; s < 24; ++s) {
-                xn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], xn, 0, 0, 0);
-                if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
-                gelu_slot(s);
-                __builtin_amdgcn_sched_barrier(0);
-                if (s == 11) CE_STAMP(2);                                  // slots 0 .. 11
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 24; ++s) gelu_slot(s);
-        }
-        gelu_finish(7);
-        CE_STAMP(3);                                                       // slots 12 .. 23 of the first product + GELU
-        if (ch + 2 < NCH) store_w1(w1_of(ch + 2));                         // (its home held W1 chunk ch, last read a barrier ago)
-        if (ch + 3 < NCH) load_w1(chunk_of(ch + 3));                       // stored by the next iteration, here
-        CE_STAMP(4);                                                       // W1 staging
-        // ---- out^T += W2 chunk . X^T(ch)
-        {
-            const unsigned short* ap = w2_of(ch) + c * CE_W2_LD + 8 * hh;
-            auto frag = [&](int i) { return *reinterpret_cast<const bf16x8*>(ap + (i >> 1) * 32 * CE_W2_LD + 16 * (i & 1)); };
-            bf16x8 af[DEPTH];
-#pragma unroll
-            for (int i = 0; i < DEPTH; ++i) af[i] = frag(i);
-#pragma unroll
-            for (int i = 0; i < 24; ++i) {                                  // i = 2 nb + s2
-                acc[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i % DEPTH], __builtin_bit_cast(bf16x8, xbw[i & 1]), acc[i >> 1], 0, 0, 0);
-                if (i + DEPTH < 24) af[i % DEPTH] = frag(i + DEPTH);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        CE_STAMP(5);                                                       // second product
-        if (more) store_w2(w2_of(ch + 1));                                 // (its home held W2 chunk ch - 1)
-        CE_STAMP(6);                                                       // W2 staging
-        lds_barrier();
-        CE_STAMP(7);                                                       // barrier
-        xc = xn;
-    }
 
-    // ---- + b2 + residual, LayerNorm over the token's 384 features (this lane: 192 of them, lane ^ 32 the others)
+    // ---- One iteration = 48 MFMA slots: out^T += W2 chunk (ch - 1) . GELU(X^T(ch - 1)) (24), then X^T(ch + 1) = W1 chunk
+    // (ch + 1) . h^T (24), with EVERYTHING else of the iteration dealt out over those slots, a few instructions each: the
+    // GELU of chunk ch (its output feeds the next iteration's second product), the LDS stores of the staged weights, the
+    // global loads of the next ones.  Why: a wave issues in order and one wave per SIMD has nobody to overlap with -- the
+    // probe (tools/probes/mfma_valu_probe.hip) and the in-kernel clocks say a 32x32x16 MFMA hides about five other
+    // instructions and every further one adds its own issue cycles, and anything bunched between two products (r03
+    // before this: iteration top 550 cycles, staging 2 x 450, GELU beside ONE product 24 x 62) runs with the matrix pipe
+    // idle.  The empty asm statements pin each piece to its slot (the compiler otherwise sinks it next to its use).
+    u32x4 xbw[2], xbp[2];                            // GELU(X^T) of chunk ch (being made) and of chunk ch - 1 (second product's B)
+    float gx[2][2], gf[2][2];
+    f32x2_t gt[2][2];
+    auto gelu_lookup = [&](int e) {                  // value e of xc: interval of the Phi table, fraction, gather
+        const int k = e >> 1, i = e & 1;
+        float x = xc[e];
+        float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(x, CE_GELU_N / (2.f * CE_GELU_R), CE_GELU_N / 2.f), 0.f, 511.99997f);
+        unsigned int off = (unsigned int)t * 8u;
+        float f = __builtin_amdgcn_fractf(t);
+        asm volatile("" : "+v"(x), "+v"(f), "+v"(off));
+        gx[k & 1][i] = x;
+        gf[k & 1][i] = f;
+        gt[k & 1][i] = *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const unsigned char*>(gtab) + off);
+    };
+    auto gelu_finish = [&](int k) {                  // pair k -> xbw
+        const float y0 = gx[k & 1][0] * __builtin_fmaf(gf[k & 1][0], gt[k & 1][0][1], gt[k & 1][0][0]);
+        const float y1 = gx[k & 1][1] * __builtin_fmaf(gf[k & 1][1], gt[k & 1][1][1], gt[k & 1][1][0]);
+        unsigned int pk = __builtin_bit_cast(unsigned int, (bf16x2_t){(__bf16)y0, (__bf16)y1});
+        asm volatile("" : "+v"(pk));
+        xbw[k >> 2][k & 3] = pk;
+    };
+    // HAS_A: second product of chunk ch - 1; HAS_G: GELU of chunk ch; HAS_B: first product of chunk ch + 1 (+ the staging)
+    auto iteration = [&](int ch, auto has_a, auto has_g, auto has_b) {
+        constexpr bool HAS_A = decltype(has_a)::value, HAS_G = decltype(has_g)::value, HAS_B = decltype(has_b)::value;
+        const unsigned short* ap2 = w2_of(ch - 1) + c * CE_W2_LD + 8 * hh;
+        const unsigned short* ap1 = w1_of(ch + 1) + c * CE_W1_LD + 8 * hh;
+        auto frag = [&](int j) {                     // A fragment of slot j
+            return j < 24 ? *reinterpret_cast<const bf16x8*>(ap2 + (j >> 1) * 32 * CE_W2_LD + 16 * (j & 1))
+                          : *reinterpret_cast<const bf16x8*>(ap1 + 16 * (j - 24));
+        };
+        constexpr int J0 = HAS_A ? 0 : 24, J1 = HAS_B ? 48 : 24;
+        f32x16 xn;
+        if (HAS_B) xn = bias_of(ch + 1);             // X^T + b1 of chunk ch + 1 starts from the bias
+        bf16x8 af[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i)
+            if (J0 + i < J1) af[i] = frag(J0 + i);
+        // the staging work of an iteration, one piece per free slot: W1 chunk ch + 2 registers -> LDS and chunk ch + 3 global ->
+        // registers, piece by piece; then W2 chunk ch and ch + 1 the same way.  (Chunk numbers past the end are clamped: a store
+        // nobody reads.)  Slot j carries a GELU piece when j % 3 == 0 (look-up of value j / 3), j == 6 k + 7 (finish of pair
+        // k, its gathers four slots old) and j == 47; the other 24 slots carry staging piece 0 .. 23.
+        const int cw1 = chunk_of(ch + 3 < NCH ? ch + 3 : NCH - 1), cw2 = chunk_of(ch + 1 < NCH ? ch + 1 : NCH - 1);
+        auto staging = [&](int n) {
+            const int i = (n % 12) >> 1, id = tid + 256 * i;
+            if (n < 12) {
+                if ((n & 1) == 0) *reinterpret_cast<u32x4*>(w1_of(ch + 2) + (id / 48) * CE_W1_LD + (id % 48) * 8) = pw[i];
+                else pw[i] = *reinterpret_cast<const u32x4*>(W1 + (int64_t)(cw1 * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
+            } else {
+                if ((n & 1) == 0) *reinterpret_cast<u32x4*>(w2_of(ch) + (id >> 2) * CE_W2_LD + (id & 3) * 8) = pw2[i];
+                else pw2[i] = *reinterpret_cast<const u32x4*>(W2p + (int64_t)(id >> 2) * CE_FFN + cw2 * CE_FFN_CH + (id & 3) * 8);
+            }
+        };
+        CE_STAMP(1);                                 // top of the iteration
+        int n_free = 0;
+#pragma unroll
+        for (int j = 0; j < 48; ++j) {
+            if (j >= J0 && j < J1) {
+                if (j < 24) acc[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(j - J0) % DEPTH], __builtin_bit_cast(bf16x8, xbp[j & 1]), acc[j >> 1], 0, 0, 0);
+                else xn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(j - J0) % DEPTH], hf[j - 24], xn, 0, 0, 0);
+                if (j + DEPTH < J1) af[(j - J0) % DEPTH] = frag(j + DEPTH);
+            }
+            const bool gelu_piece = j % 3 == 0 || (j % 6 == 1 && j >= 7) || j == 47;
+            if (gelu_piece) {
+                if (HAS_G) {
+                    if (j % 3 == 0) gelu_lookup(j / 3);
+                    else if (j == 47) gelu_finish(7);
+                    else gelu_finish((j - 7) / 6);
+                }
+            } else {
+                if (HAS_B || (HAS_G && n_free >= 12)) staging(n_free);      // (the last chunk's W2 rows are still needed; W1 rows are not)
+                ++n_free;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 23) CE_STAMP(2);                // slots 0 .. 23
+        }
+        CE_STAMP(3);                                 // slots 24 .. 47
+        lds_barrier();
+        CE_STAMP(4);                                 // barrier
+        if (HAS_B) xc = xn;
+        xbp[0] = xbw[0];
+        xbp[1] = xbw[1];
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+    iteration(0, no(), yes(), yes());
+    for (int ch = 1; ch + 1 < NCH; ++ch) iteration(ch, yes(), yes(), yes());
+    iteration(NCH - 1, yes(), yes(), no());
+    iteration(NCH, yes(), no(), no());
+
+    // ---- + b2, LayerNorm over the token's 384 features (this lane: 192 of them, lane ^ 32 the others)
     float sum = 0.f;
 #pragma unroll
     for (int nb = 0; nb < 12; ++nb)
@@ -619,10 +636,9 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         for (int g = 0; g < 4; ++g) {
             const int n = nb * 32 + 8 * g + 4 * hh;
             const f32x4 bv = *reinterpret_cast<const f32x4*>(eps_ + n);            // (LDS: two addresses per wave-instruction)
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(h32 + tok * CE_H + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = (acc[nb][4 * g + r] + bv[r]) + rv[r];
+                const float v = acc[nb][4 * g + r] + bv[r];                     // (the residual is in the accumulator already)
                 acc[nb][4 * g + r] = v;
                 sum += v;
             }
@@ -636,32 +652,138 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         for (int e = 0; e < 16; ++e) { const float d = acc[nb][e] - mean; var += d * d; }
     var += __shfl_xor(var, 32, 64);
     const float rstd = rsqrtf(var * (1.f / CE_H) + ln_eps);
-    if (live) {
+    // The normalised rows leave through LDS, 32 features at a time: the accumulator layout (lane = token, 16-byte pieces 32
+    // bytes apart) would store 32 partial lines per instruction; read back with eight lanes per token every store
+    // instruction writes eight whole 128-byte lines (fp32 row) / 64-byte runs (bf16 row).  The wave's own 32 x 36-float
+    // patch of the (now idle) chunk buffers, no barrier: a wave's LDS operations execute in order.  Lanes past M hold row
+    // M - 1 again and write the same bytes to it.
+    {
+        float* tb = reinterpret_cast<float*>(ce_smem) + wave * (32 * 36);
+        const int64_t tlast = (int64_t)M - 1;
 #pragma unroll
-        for (int nb = 0; nb < 12; ++nb)
+        for (int nb = 0; nb < 12; ++nb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nb * 32 + 8 * g + 4 * hh;
                 const f32x4 gv = *reinterpret_cast<const f32x4*>(eps_ + CE_H + n);
                 const f32x4 be = *reinterpret_cast<const f32x4*>(eps_ + 2 * CE_H + n);
                 f32x4 y;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = (acc[nb][4 * g + r] - mean) * rstd * gv[r] + be[r];
+                *reinterpret_cast<f32x4*>(tb + c * 36 + 8 * g + 4 * hh) = y;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = (lane >> 3) + 8 * j, pc = lane & 7;
+                const f32x4 y = *reinterpret_cast<const f32x4*>(tb + t * 36 + 4 * pc);
+                int64_t row = tok0 + t;
+                row = row < tlast ? row : tlast;
                 bf16x4 yb;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    y[r] = (acc[nb][4 * g + r] - mean) * rstd * gv[r] + be[r];
-                    yb[r] = (__bf16)y[r];
-                }
-                *reinterpret_cast<f32x4*>(h32 + tok * CE_H + n) = y;
-                *reinterpret_cast<bf16x4*>(hb + tok * CE_H + n) = yb;
+                for (int r = 0; r < 4; ++r) yb[r] = (__bf16)y[r];
+                *reinterpret_cast<f32x4*>(h32 + row * CE_H + nb * 32 + 4 * pc) = y;
+                *reinterpret_cast<bf16x4*>(hb + row * CE_H + nb * 32 + 4 * pc) = yb;
             }
+        }
     }
 #ifdef RR_DEBUG_HARNESS
-    CE_STAMP(8);                                                           // bias + residual + LayerNorm + stores
+    CE_STAMP(5);                                                           // bias + residual + LayerNorm + stores
     if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 600)) {
         dbg_t[9] = wall_clock64() - dbg_w0;
         for (int i = 0; i < 10; ++i) ce_dbg_ffn[blockIdx.x ? 1 : 0][i] = dbg_t[i];
     }
 #endif
+}
+
+// ------------------------------------------------------------------ QKV projection, token-stationary: out = bf16(h W^T + b)
+// The first product of ce_ffn_fused without anything behind it: a wave's 32 tokens sit on the MFMA columns for the whole
+// kernel (their bf16 rows = 24 B fragments in registers, loaded once), the weight rows stream through LDS in chunks of 32
+// output features, X^T[j][tok] = W[j] . h[tok] + b[j] leaves the accumulator as bf16x4 pieces (features 8 g + 4 hh .. + 3
+// of the token's row: lane halves hh = 0, 1 of a token write 16 adjacent bytes).  EIGHT waves per workgroup, two per SIMD
+// (96 + 2 x 16 + staging registers: under 256): what one wave cannot overlap with its own MFMAs -- a wave issues in order,
+// tools/probes/mfma_valu_probe.hip -- the other wave's MFMAs cover.  (r02 built this with one wave per SIMD: 262 us per
+// layer against the tiled GEMM's 222.)  256 tokens per workgroup; a chunk's store pieces and the staging of the next
+// chunks are dealt out over the 24 MFMA slots of the chunk after it.
+#define CE_QKV_TOK 256
+#define CE_QKV_LDS(N) (2 * CE_FFN_CH * CE_W1_LD * 2 + (N) * 4)
+template <int DEPTH>
+__global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restrict__ hb, int M, const unsigned short* __restrict__ W,
+                                                   const float* __restrict__ bias, int N, unsigned short* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
+    unsigned short* wbuf = reinterpret_cast<unsigned short*>(ce_smem);          // [2][32][CE_W1_LD]
+    float* bs = reinterpret_cast<float*>(wbuf + 2 * CE_FFN_CH * CE_W1_LD);      // [N]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, hh = lane >> 5;
+    int64_t tok = (int64_t)blockIdx.x * CE_QKV_TOK + wave * 32 + c;
+    tok = tok < M ? tok : M - 1;
+    bf16x8 hf[24];
+#pragma unroll
+    for (int s = 0; s < 24; ++s) hf[s] = *reinterpret_cast<const bf16x8*>(hb + tok * CE_H + 16 * s + 8 * hh);
+    for (int i = tid; i < N / 4; i += 512) reinterpret_cast<f32x4*>(bs)[i] = reinterpret_cast<const f32x4*>(bias)[i];
+    // a chunk = 32 rows x 768 B = 1536 pieces of 16 B, three per thread
+    u32x4 pw[3];
+    const int nch = N / CE_FFN_CH;
+    auto load_w = [&](int k, int i) {
+        const int id = tid + 512 * i;
+        pw[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)(k * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
+    };
+    auto store_w = [&](int k, int i) {
+        const int id = tid + 512 * i;
+        *reinterpret_cast<u32x4*>(wbuf + (k & 1) * CE_FFN_CH * CE_W1_LD + (id / 48) * CE_W1_LD + (id % 48) * 8) = pw[i];
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+#pragma unroll
+    for (int i = 0; i < 3; ++i) load_w(0, i);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) store_w(0, i);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) load_w(nch > 1 ? 1 : 0, i);
+    lds_barrier();
+    auto bias_of = [&](int k) {
+        f32x16 v;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(bs + k * CE_FFN_CH + 8 * g + 4 * hh);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * g + r] = q[r];
+        }
+        return v;
+    };
+    unsigned short* orow = out + tok * N + 4 * hh;
+    f32x16 prev;
+    auto put = [&](int k, int g) {                   // features 8 g + 4 hh .. + 3 of chunk k, from `prev`
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (__bf16)prev[4 * g + r];
+        *reinterpret_cast<bf16x4*>(orow + k * CE_FFN_CH + 8 * g) = v;        // (lanes past M hold row M - 1 again: the same bytes)
+    };
+    for (int k = 0; k < nch; ++k) {
+        const unsigned short* ap = wbuf + (k & 1) * CE_FFN_CH * CE_W1_LD + c * CE_W1_LD + 8 * hh;
+        f32x16 acc = bias_of(k);
+        bf16x8 af[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + 16 * i);
+        const int kn = k + 2 < nch ? k + 2 : nch - 1;
+#pragma unroll
+        for (int s = 0; s < 24; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], acc, 0, 0, 0);
+            if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
+            // slots 1, 5, 9: chunk k + 1 registers -> LDS (its home held chunk k - 1, read before the last barrier);
+            // slots 3, 7, 11: chunk k + 2 global -> registers; slots 14, 16, 18, 20: the previous chunk's output
+            if (s == 1 || s == 5 || s == 9) store_w(k + 1, (s - 1) >> 2);
+            if (s == 3 || s == 7 || s == 11) load_w(kn, (s - 3) >> 2);
+            if (k > 0 && s >= 14 && s <= 20 && (s & 1) == 0) put(k - 1, (s - 14) >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier();
+        prev = acc;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) put(nch - 1, g);
 }
 
 // ------------------------------------------------------------------ attention: one workgroup per (sequence, head)
@@ -1270,6 +1392,7 @@ static int ce_set_attributes(int device) {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512)));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
 #ifdef RR_DEBUG_HARNESS
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
 #endif
@@ -1362,6 +1485,7 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     const size_t ldsP = 8 * 64 * (96 + 8) * 2;          // plain epilogues stage eight 64 x 96 sub-tiles (> the K-tile buffers)
     const size_t ldsF = (size_t)CE_FFN_LDS;     // fused FFN: two chunk buffers + biases / LayerNorm rows + the Phi table
     static const bool unfused = getenv("RR_CE_UNFUSED") != nullptr;   // A/B: FFN as two GEMM launches
+    static const bool qkv_tiled = getenv("RR_CE_QKV_TILED") != nullptr;   // A/B: the QKV projection as the tiled GEMM
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
         // The last layer of a [CLS]-pooled output (logits, CLS embedding) needs keys and values of every token but
@@ -1376,8 +1500,12 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
         // (the transposed, token-persistent form of the fused FFN was also built for these two projections and measured
         //  slower than the tiled GEMM: QKV 262 vs 222 us, attention output 154 vs 124 us per layer at 131 072 tokens -- with
         //  nothing to fuse, one wave per SIMD loses to eight waves per tile)
-        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 384)), dim3(512), ldsP, st, ce->hb, L.wqkv,
-                           L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
+        if (qkv_tiled)
+            hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 384)), dim3(512), ldsP, st, ce->hb, L.wqkv,
+                               L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
+        else
+            hipLaunchKernelGGL((ce_proj_ts<4>), dim3((unsigned)((T + CE_QKV_TOK - 1) / CE_QKV_TOK)), dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T,
+                               L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
         hipLaunchKernelGGL(ce_attention, dim3((unsigned)n_seqs, CE_HEADS), dim3(CE_ATT_THREADS), ce_attention_lds(smax_pad), st,
                            ce->qkv, d_cu_seqlens, ce->ctx, 0.17677669529663687f /* 1 / sqrt(32) */, smax_pad,
                            cls_tail ? ce->ctxc : (unsigned short*)nullptr);
@@ -1424,7 +1552,7 @@ extern "C" int rr_ce_last_forward_ms(rr_ce* ce, float* out_ms) {
 
 #ifdef RR_DEBUG_HARNESS
 // tools/k5_stamps.py: phase clocks of the LAST ce_ffn_fused launch (wave 0 of workgroups 0 and 600): per workgroup
-// [prologue, iteration top, slots 0-11, slots 12-23, W1 staging, product 2, W2 staging, barrier, epilogue] shader cycles + wall_clock64 ticks (100 MHz)
+// [prologue, iteration top, slots 0-23, slots 24-47, barrier, epilogue, -, -, -] shader cycles + wall_clock64 ticks (100 MHz)
 extern "C" int rr_debug_ce_ffn_stamps(unsigned long long* out20) {
     RR_HIP_TRY(hipDeviceSynchronize());
     RR_HIP_TRY(hipMemcpyFromSymbol(out20, HIP_SYMBOL(ce_dbg_ffn), sizeof(unsigned long long) * 20));

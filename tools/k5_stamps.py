@@ -20,14 +20,14 @@ def main():
     print(f"forward (2 layers) {ce.model.last_forward_ms():.3f} ms")
     out = (C.c_uint64 * 20)()
     _lib.check(lib.rr_debug_ce_ffn_stamps(out), "rr_debug_ce_ffn_stamps")
-    names = ["prologue", "iteration top", "slots 0-11", "slots 12-23", "w1 staging", "product2", "w2 staging", "barrier", "epilogue"]
+    names = ["prologue", "iteration top", "slots 0-23 (second product)", "slots 24-47 (first product)", "barrier", "epilogue", "-", "-", "-"]
     for w in range(2):
         v = [out[10 * w + i] for i in range(10)]
         tot = sum(v[:9])
         us = v[9] / 100.0
-        print(f"workgroup {(0, 600)[w]}: {tot} cycles in {us:.1f} us = {tot / us / 1e3:.2f} GHz; per chunk (48): "
-              + ", ".join(f"{n} {v[i] / 48:.0f}" for i, n in enumerate(names) if 1 <= i <= 7)
-              + f"; prologue {v[0]}, epilogue {v[8]}")
+        print(f"workgroup {(0, 600)[w]}: {tot} cycles in {us:.1f} us = {tot / us / 1e3:.2f} GHz; per iteration (49): "
+              + ", ".join(f"{n} {v[i] / 49:.0f}" for i, n in enumerate(names) if 1 <= i <= 4)
+              + f"; prologue {v[0]}, epilogue {v[5]}")
 
 
 if __name__ == "__main__":
