@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
 #define CE_FFN_BUF (CE_FFN_CH * CE_W1_LD + CE_H * CE_W2_LD)     // bf16 elements per chunk buffer
 #define CE_GELU_N 512           // intervals of the fused FFN's Phi table over [-CE_GELU_R, CE_GELU_R]
 #define CE_GELU_R 4.5f
-#define CE_FFN_LDS (2 * CE_FFN_BUF * 2 + CE_FFN * 4 + 3 * CE_H * 4 + CE_GELU_N * 8)   // two chunk buffers + b1 + (b2, ln_g, ln_b) + the Phi table
+#define CE_FFN_LDS (2 * CE_FFN_BUF * 2 + CE_FFN * 4 + 6 * CE_H * 4 + CE_GELU_N * 8)   // two chunk buffers + b1 + (b2, ln_g, ln_b) + the Phi table + (bo, ln1_g, ln1_b)
 
 // DEPTH: A fragments in flight.  STAGGER rotates the chunk order per workgroup (it spreads the L2 lines the CUs ask for at
 // one time, but makes a token's rounding depend on where it sits in the batch): measured r02 at 256 x 512 tokens, whole
@@ -404,13 +404,20 @@ __device__ unsigned long long ce_dbg_ffn[2][10];
 #define CE_STAMP(slot) do { } while (0)
 #endif
 
-template <int DEPTH, bool STAGGER>
+// OPROJ: the attention output projection + residual + first LayerNorm run in front, in the same transposed form (the rows of
+// `ctx` are the B fragments, Wo streams through the W1 chunk buffers, out^T accumulates on top of the residual): the
+// normalised rows stay in the accumulators as the second LayerNorm's residual and become the FFN's B fragments by one
+// v_permlane32_swap per two dwords -- the [T][384] fp32 + bf16 round trip through HBM between the two kernels, the second
+// kernel's row loads and the first one's row stores are gone.
+template <int DEPTH, bool STAGGER, bool OPROJ>
 __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     unsigned short* __restrict__ hb, float* __restrict__ h32, int M,
     const unsigned short* __restrict__ W1, const float* __restrict__ b1,       // [1536][384], [1536]
     const unsigned short* __restrict__ W2p, const float* __restrict__ b2,      // [384][1536] columns permuted, [384]
     const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
-    const float* __restrict__ gelu_tab) {                                       // [CE_GELU_N][2]: ce_gelu_table
+    const float* __restrict__ gelu_tab,                                         // [CE_GELU_N][2]: ce_gelu_table
+    const unsigned short* __restrict__ ctx, const unsigned short* __restrict__ Wo, const float* __restrict__ bo,
+    const float* __restrict__ ln1_g, const float* __restrict__ ln1_b) {         // OPROJ only: [M][384], [384][384], 3 x [384]
     extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
     unsigned short* wbuf = reinterpret_cast<unsigned short*>(ce_smem);          // [2][CE_FFN_BUF]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     // the tokens' rows as B fragments: lane (c, hh), K-step s holds hb[tok][16 s + 8 hh .. + 7]
     bf16x8 hf[24];
 #pragma unroll
-    for (int s = 0; s < 24; ++s) hf[s] = *reinterpret_cast<const bf16x8*>(hb + tok * CE_H + 16 * s + 8 * hh);
+    for (int s = 0; s < 24; ++s) hf[s] = *reinterpret_cast<const bf16x8*>((OPROJ ? ctx : hb) + tok * CE_H + 16 * s + 8 * hh);
 
     // out^T accumulates ON TOP of the token's residual row: its 48 loads are in flight under the staging of the first chunks
     // instead of standing, all workgroups at once, between the last MFMA and the LayerNorm (r03 in-kernel clocks: the
@@ -497,6 +504,102 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     for (int i = tid; i < 3 * CE_H / 4; i += 256) {
         const float* src = i < CE_H / 4 ? b2 : i < 2 * CE_H / 4 ? ln_g : ln_b;
         reinterpret_cast<f32x4*>(eps_)[i] = reinterpret_cast<const f32x4*>(src)[i % (CE_H / 4)];
+    }
+    float* eps1_ = gtab + 2 * CE_GELU_N;                                        // [3][384] bo, ln1_g, ln1_b (OPROJ)
+    if (OPROJ) {
+        for (int i = tid; i < 3 * CE_H / 4; i += 256) {
+            const float* src = i < CE_H / 4 ? bo : i < 2 * CE_H / 4 ? ln1_g : ln1_b;
+            reinterpret_cast<f32x4*>(eps1_)[i] = reinterpret_cast<const f32x4*>(src)[i % (CE_H / 4)];
+        }
+        // ---- out^T = residual + Wo . ctx^T: twelve chunks of 32 output features, 24 MFMAs each into the chunk's accumulator
+        auto load_wo = [&](int k, int i) {
+            const int id = tid + 256 * i;
+            pw[i] = *reinterpret_cast<const u32x4*>(Wo + (int64_t)(k * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
+        };
+        auto store_wo = [&](int k, int i) {
+            const int id = tid + 256 * i;
+            *reinterpret_cast<u32x4*>(w1_of(k) + (id / 48) * CE_W1_LD + (id % 48) * 8) = pw[i];
+        };
+#pragma unroll
+        for (int i = 0; i < 6; ++i) load_wo(0, i);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) store_wo(0, i);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) load_wo(1, i);
+        lds_barrier();
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb) {
+            const unsigned short* ap = w1_of(nb) + c * CE_W1_LD + 8 * hh;
+            bf16x8 af[DEPTH];
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + 16 * i);
+#pragma unroll
+            for (int s = 0; s < 24; ++s) {
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], acc[nb], 0, 0, 0);
+                if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
+                if (s % 4 == 1 && nb + 1 < 12) store_wo(nb + 1, s >> 2);       // (its home held chunk nb - 1, read a barrier ago)
+                if (s % 4 == 3 && nb + 2 < 12) load_wo(nb + 2, s >> 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_barrier();
+        }
+        // ---- + bo, first LayerNorm (statistics over the lane pair, as at the end of the kernel)
+        int h4 = 4 * hh;
+        asm volatile("" : "+v"(h4));          // (its own copy: addresses shared with the kernel's last phase would live -- spilled -- across the whole FFN)
+        float sum1 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(eps1_ + nb * 32 + 8 * g + h4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[nb][4 * g + r] += bv[r];
+                    sum1 += acc[nb][4 * g + r];
+                }
+            }
+        sum1 += __shfl_xor(sum1, 32, 64);
+        const float mean1 = sum1 * (1.f / CE_H);
+        float var1 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float d = acc[nb][e] - mean1; var1 += d * d; }
+        var1 += __shfl_xor(var1, 32, 64);
+        const float rstd1 = rsqrtf(var1 * (1.f / CE_H) + ln_eps);
+        // the normalised row: fp32 in the accumulators (the residual the second product adds to) and, rounded to bf16, the
+        // FFN's B fragments.  Lane half hh holds features 8 g + 4 hh .. + 3 of each 32; fragment s wants 16 s + 8 hh .. + 7:
+        // half 0 keeps its group 2 (s & 1) and takes half 1's, half 1 keeps its group 2 (s & 1) + 1 and takes half 0's --
+        // v_permlane32_swap exchanges exactly those (first operand's upper 32 lanes <-> second operand's lower 32)
+#pragma unroll
+        for (int nb = 0; nb < 12; ++nb) {
+            unsigned int pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nb * 32 + 8 * g + h4;
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(eps1_ + CE_H + n);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(eps1_ + 2 * CE_H + n);
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = (acc[nb][4 * g + r] - mean1) * rstd1 * gv[r] + be[r];
+                    acc[nb][4 * g + r] = y[r];
+                }
+                pk[g][0] = __builtin_bit_cast(unsigned int, (bf16x2_t){(__bf16)y[0], (__bf16)y[1]});
+                pk[g][1] = __builtin_bit_cast(unsigned int, (bf16x2_t){(__bf16)y[2], (__bf16)y[3]});
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                u32x4 f;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(pk[2 * half][d], pk[2 * half + 1][d], false, false);
+                    f[d] = r[0];
+                    f[2 + d] = r[1];
+                }
+                hf[2 * nb + half] = __builtin_bit_cast(bf16x8, f);
+            }
+        }
     }
     load_w1(chunk_of(0)); store_w1(w1_of(0));
     load_w1(chunk_of(1)); store_w1(w1_of(1));
@@ -705,7 +808,7 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 // layer against the tiled GEMM's 222.)  256 tokens per workgroup; a chunk's store pieces and the staging of the next
 // chunks are dealt out over the 24 MFMA slots of the chunk after it.
 #define CE_QKV_TOK 256
-#define CE_QKV_LDS(N) (2 * CE_FFN_CH * CE_W1_LD * 2 + (N) * 4)
+#define CE_QKV_LDS(N) (2 * CE_FFN_CH * CE_W1_LD * 2 + (N) * 4 + 8 * 32 * 80)
 template <int DEPTH>
 __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restrict__ hb, int M, const unsigned short* __restrict__ W,
                                                    const float* __restrict__ bias, int N, unsigned short* __restrict__ out) {
@@ -753,13 +856,25 @@ __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restri
         }
         return v;
     };
-    unsigned short* orow = out + tok * N + 4 * hh;
+    // a chunk's 32 tokens x 32 features leave through the wave's own LDS patch ([token][64 B + 16 pad]): written as the
+    // accumulator holds them (8-byte pieces), read back with four lanes per token, so that a store instruction writes 16
+    // rows x 64 contiguous bytes instead of 32 rows x 16 (the scattered form cost ~2 000 of a chunk's ~5 000 cycles in
+    // the address path).  No barrier: a wave's LDS operations execute in order.
+    unsigned char* tp = reinterpret_cast<unsigned char*>(bs + N) + wave * (32 * 80);
+    const int64_t row0 = (int64_t)blockIdx.x * CE_QKV_TOK + wave * 32, rlast = (int64_t)M - 1;
     f32x16 prev;
-    auto put = [&](int k, int g) {                   // features 8 g + 4 hh .. + 3 of chunk k, from `prev`
+    auto put_lds = [&](int g) {                      // features 8 g + 4 hh .. + 3 of the previous chunk, from `prev`
         bf16x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (__bf16)prev[4 * g + r];
-        *reinterpret_cast<bf16x4*>(orow + k * CE_FFN_CH + 8 * g) = v;        // (lanes past M hold row M - 1 again: the same bytes)
+        *reinterpret_cast<bf16x4*>(tp + c * 80 + 16 * g + 8 * hh) = v;
+    };
+    auto put_rows = [&](int k, int j) {              // tokens 16 j .. 16 j + 15 of chunk k: lane = (token, 16-byte piece)
+        const int t = 16 * j + (lane >> 2), pc = lane & 3;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(tp + t * 80 + 16 * pc);
+        int64_t row = row0 + t;
+        row = row < rlast ? row : rlast;             // (lanes past M hold row M - 1 again: the same bytes)
+        *reinterpret_cast<u32x4*>(out + row * N + k * CE_FFN_CH + 8 * pc) = v;
     };
     for (int k = 0; k < nch; ++k) {
         const unsigned short* ap = wbuf + (k & 1) * CE_FFN_CH * CE_W1_LD + c * CE_W1_LD + 8 * hh;
@@ -773,17 +888,20 @@ __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restri
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % DEPTH], hf[s], acc, 0, 0, 0);
             if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
             // slots 1, 5, 9: chunk k + 1 registers -> LDS (its home held chunk k - 1, read before the last barrier);
-            // slots 3, 7, 11: chunk k + 2 global -> registers; slots 14, 16, 18, 20: the previous chunk's output
+            // slots 3, 7, 11: chunk k + 2 global -> registers; slots 13 .. 16 and 19, 21: the previous chunk's output
             if (s == 1 || s == 5 || s == 9) store_w(k + 1, (s - 1) >> 2);
             if (s == 3 || s == 7 || s == 11) load_w(kn, (s - 3) >> 2);
-            if (k > 0 && s >= 14 && s <= 20 && (s & 1) == 0) put(k - 1, (s - 14) >> 1);
+            if (k > 0 && s >= 13 && s <= 16) put_lds(s - 13);
+            if (k > 0 && (s == 19 || s == 21)) put_rows(k - 1, (s - 19) >> 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier();
         prev = acc;
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) put(nch - 1, g);
+    for (int g = 0; g < 4; ++g) put_lds(g);
+    put_rows(nch - 1, 0);
+    put_rows(nch - 1, 1);
 }
 
 // ------------------------------------------------------------------ attention: one workgroup per (sequence, head)
@@ -1391,10 +1509,11 @@ static int ce_set_attributes(int device) {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsP));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsB));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512)));
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
 #ifdef RR_DEBUG_HARNESS
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
 #endif
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * (CE_F32_KLD + CE_HD) * 4));
     done[device] = true;
@@ -1486,6 +1605,7 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     const size_t ldsF = (size_t)CE_FFN_LDS;     // fused FFN: two chunk buffers + biases / LayerNorm rows + the Phi table
     static const bool unfused = getenv("RR_CE_UNFUSED") != nullptr;   // A/B: FFN as two GEMM launches
     static const bool qkv_tiled = getenv("RR_CE_QKV_TILED") != nullptr;   // A/B: the QKV projection as the tiled GEMM
+    static const bool oproj_apart = getenv("RR_CE_OPROJ_APART") != nullptr;   // A/B: attention output + LayerNorm as its own launch
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
         // The last layer of a [CLS]-pooled output (logits, CLS embedding) needs keys and values of every token but
@@ -1510,18 +1630,28 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
                            ce->qkv, d_cu_seqlens, ce->ctx, 0.17677669529663687f /* 1 / sqrt(32) */, smax_pad,
                            cls_tail ? ce->ctxc : (unsigned short*)nullptr);
         if (cls_tail) hipLaunchKernelGGL(ce_gather_cls, dim3((unsigned)n_seqs), dim3(128), 0, st, ce->h32, d_cu_seqlens, ce->h32c);
-        hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rctx, L.wo, L.bo, Mr, CE_H,
-                           CE_H, rb, r32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
-        if (!unfused) {
+        const bool oproj_fused = !unfused && !oproj_apart;
+        if (!oproj_fused)
+            hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_RES_LN>), dim3(ce_grid(Mr, 128, 1)), dim3(512), ldsB, st, rctx, L.wo, L.bo, Mr, CE_H,
+                               CE_H, rb, r32, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
+        if (oproj_fused) {
+            // attention output projection + residual + LayerNorm + FFN + residual + LayerNorm: one launch
+            const dim3 fg((unsigned)((Mr + CE_FFN_TOK - 1) / CE_FFN_TOK));
+            hipLaunchKernelGGL((ce_ffn_fused<4, false, true>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
+                               L.ln2_b, ce->cfg.ln_eps, ce->gelu_tab, (const unsigned short*)rctx, (const unsigned short*)L.wo, (const float*)L.bo,
+                               (const float*)L.ln1_g, (const float*)L.ln1_b);
+        } else if (!unfused) {
             const dim3 fg((unsigned)((Mr + CE_FFN_TOK - 1) / CE_FFN_TOK));
 #ifdef RR_DEBUG_HARNESS
             static const bool depth8 = getenv("RR_CE_FFN_DEPTH8") != nullptr;      // (tools/k5_stamps.py: A fragments 8 slots ahead)
-            if (depth8) hipLaunchKernelGGL((ce_ffn_fused<8, false>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
-                                           L.ln2_b, ce->cfg.ln_eps, ce->gelu_tab);
+            if (depth8) hipLaunchKernelGGL((ce_ffn_fused<8, false, false>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
+                                           L.ln2_b, ce->cfg.ln_eps, ce->gelu_tab, (const unsigned short*)nullptr, (const unsigned short*)nullptr, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr);
             else
 #endif
-            hipLaunchKernelGGL((ce_ffn_fused<4, false>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
-                               L.ln2_b, ce->cfg.ln_eps, ce->gelu_tab);
+            hipLaunchKernelGGL((ce_ffn_fused<4, false, false>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
+                               L.ln2_b, ce->cfg.ln_eps, ce->gelu_tab, (const unsigned short*)nullptr, (const unsigned short*)nullptr, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr);
         } else {
             hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_GELU>), dim3(ce_grid(Mr, 128, CE_FFN / 384)), dim3(512), ldsP, st, rb, L.w1, L.b1, Mr,
                                CE_FFN, CE_H, rint, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);

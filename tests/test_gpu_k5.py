@@ -297,3 +297,35 @@ def test_cli_runs_offline_from_local_model_directories(tmp_path, capsys):
         assert abs(g["score"] - e["score"]) <= tol
         for key in ("dense", "bm25", "prior"):
             assert abs(g[key] - e[key]) <= 1.01e-4
+
+
+K5_SWITCH_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from review_recommender_amd import synth
+from review_recommender_amd.cross_encoder import CrossEncoder
+fx = np.load(%r)
+cu = fx["cu_seqlens"]
+seqs = [(fx["token_ids"][cu[i]:cu[i + 1]], fx["type_ids"][cu[i]:cu[i + 1]]) for i in range(len(cu) - 1)]
+ce = CrossEncoder(synth.bert_state_dict(int(fx["seed"]), n_layers=6, n_labels=1), precision="bf16")
+print("LOGITS " + " ".join(repr(float(v)) for v in ce.predict_ids(seqs)))
+"""
+
+
+@pytest.mark.parametrize("switch", ["RR_CE_QKV_TILED", "RR_CE_OPROJ_APART", "RR_CE_UNFUSED"])
+def test_bf16_path_switches_stay_inside_the_bf16_bar(ce_world, switch):
+    """The A/B forms of the fast path (the QKV projection as the tiled GEMM; the attention output projection + LayerNorm as
+    its own launch; the FFN as two GEMM launches with the polynomial GELU) are read once per process: each runs the fixture in a child and must meet the same bar as the
+    default form, and agree with it to bf16 rounding."""
+    import os
+    import subprocess
+    import sys
+    fx, sd, ce = ce_world
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = K5_SWITCH_CHILD % (root, str(GOLDEN / "k5_cross_encoder.npz"))
+    p = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, **{switch: "1"}), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = np.array([float(v) for v in [l for l in p.stdout.splitlines() if l.startswith("LOGITS ")][-1].split()[1:]], dtype=np.float32)
+    assert np.abs(got - fx["logits"]).max() < LOGIT_TOL
+    assert np.abs(got - ce.predict_ids(split(fx))).max() < LOGIT_TOL
