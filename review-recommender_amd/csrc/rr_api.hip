@@ -155,6 +155,7 @@ extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim
         if (e == hipSuccess) e = hipEventCreate(&ix->ring1[i]);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_sel_trace, sizeof(int32_t) * 16 * RR_SEL_MAXQ);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_flag_list, sizeof(int32_t) * 16);
     if (e == hipSuccess) e = hipMalloc(&ix->d_qplanes, (size_t)2 * 3 * 64 * 384 * 2)   /* two sets of query planes (paired filter-scan launches) */;
     if (e == hipSuccess) e = hipMalloc(&ix->d_x3, rr_x3_scratch_bytes());
     if (e == hipSuccess) e = hipMalloc(&ix->d_q, sizeof(float) * (size_t)RR_MAX_BATCH * ix->dim_pad);
@@ -277,7 +278,7 @@ extern "C" int rr_index_destroy(rr_index* ix) {
     if (ix->stream) hipStreamSynchronize(ix->stream);
     if (ix->d_matrix && ix->owns_matrix) hipFree(ix->d_matrix);
     hipFree(ix->d_n_reviews); hipFree(ix->d_avg_stars); hipFree(ix->d_log1p_n);
-    hipFree(ix->d_sims); hipFree(ix->d_gmax); hipFree(ix->d_smax); hipFree(ix->d_sel_trace); hipFree(ix->d_qplanes); hipFree(ix->d_x3); hipFree(ix->d_q);
+    hipFree(ix->d_sims); hipFree(ix->d_gmax); hipFree(ix->d_smax); hipFree(ix->d_sel_trace); hipFree(ix->d_flag_list); hipFree(ix->d_qplanes); hipFree(ix->d_x3); hipFree(ix->d_q);
     hipFree(ix->d_rows_out); hipFree(ix->d_scores_out); hipFree(ix->d_shadow); hipFree(ix->d_flt_samp); hipFree(ix->d_flt_sigma); hipFree(ix->d_flt_prog); free(ix->flt_pending);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);

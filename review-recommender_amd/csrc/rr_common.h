@@ -49,6 +49,7 @@ struct rr_index {
     float* d_sims = nullptr;     // [qcap][n_pad]
     float* d_gmax = nullptr;     // [qcap][n_tiles]
     int32_t* d_sel_trace = nullptr;  // [8][4] path trace of the last selection launch
+    int32_t* d_flag_list = nullptr;  // [16] count + the (at most 8) flagged queries of a filter call served by the single-query chain
     uint32_t* d_smax = nullptr;  // [qcap][n_super] ordered keys of super-tile maxima
     int32_t scratch_q = 0;
     float* d_q = nullptr;        // staged queries [RR_MAX_BATCH][dim_pad]

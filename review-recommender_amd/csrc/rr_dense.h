@@ -48,6 +48,8 @@ int rr_scan_events_begin(rr_index* ix, hipStream_t st);
 void rr_scan_events_end(rr_index* ix, int slot, hipStream_t st);
 // Exact top-pool of `nq` queries from the three score levels a scan left in the index scratch.
 // `only_if` (device, one flag per query, may be null): queries whose flag is 0 are skipped.
+int rr_dense_listed_fallback(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows, float* d_scores,
+                             int32_t* flags, hipStream_t st);
 void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                       float* d_scores, hipStream_t st, const int32_t* only_if = nullptr, int slices = 1,
                       int64_t sims_slice = 0, int64_t gmax_slice = 0, int64_t smax_slice = 0);

@@ -93,14 +93,58 @@ __device__ __forceinline__ void rr_finish_tile(const rr_scan_geom& G, int64_t ti
     }
 }
 
-template <int NF, int NB>
+// The (at most NB) first queries of a call whose flag is up: every wave works the list out for itself (four coalesced
+// loads + ballots), so that no launch stands between the flags and their readers.  Returns the count; slots past it
+// repeat the last query.
+template <int NB>
+__device__ __forceinline__ int rr_flagged_list(const int32_t* __restrict__ flags, int nq, int lane, int (&list)[NB]) {
+    int n = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) list[b] = 0;
+    for (int i = 0; i < (nq + 63) / 64 && n < NB; ++i) {
+        const int q = 64 * i + lane;
+        unsigned long long m = __ballot(q < nq && flags[q] != 0);
+        while (m && n < NB) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (j == n) list[j] = 64 * i + b;
+            ++n;
+        }
+    }
+#pragma unroll
+    for (int j = 1; j < NB; ++j)
+        if (j >= n && n > 0) list[j] = list[j - 1];
+    return n;
+}
+
+// LISTED: the queries are the first (at most NB) of `queries` whose flag is up (the filter path's flagged queries, served
+// by this kernel's per-row chain: bit for bit the single-query answer); nothing flagged -> every workgroup returns at once.
+template <int NF, int NB, bool LISTED = false>
 __global__ __launch_bounds__(RR_SCAN_THREADS, (NB <= 1 ? 4 : 2)) void rr_scan_f32(
     const f32x4* __restrict__ mat, rr_scan_geom G, const float* __restrict__ queries,  // NB x (NF*64)
-    float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax) {
+    float* __restrict__ sims, float* __restrict__ gmax, uint32_t* __restrict__ smax,
+    const int32_t* __restrict__ flags = nullptr, int nq_total = 0, int32_t* __restrict__ list_out = nullptr) {
     __shared__ f32x4 qs[NB][NF * 16];
     const int tid = threadIdx.x;
-    for (int i = tid; i < NB * NF * 16; i += RR_SCAN_THREADS)
-        qs[i / (NF * 16)][i % (NF * 16)] = reinterpret_cast<const f32x4*>(queries)[i];
+    if (LISTED) {
+        int list[NB];
+        const int n = rr_flagged_list<NB>(flags, nq_total, tid & 63, list);
+        if (blockIdx.x == 0 && tid == 0) {
+            list_out[0] = n;                          // (also when it is 0: the selection behind this launch reads it)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) list_out[1 + b] = list[b];
+        }
+        if (n == 0) return;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            for (int i = tid; i < NF * 16; i += RR_SCAN_THREADS)
+                qs[b][i] = reinterpret_cast<const f32x4*>(queries)[(int64_t)list[b] * (NF * 16) + i];
+    } else {
+        for (int i = tid; i < NB * NF * 16; i += RR_SCAN_THREADS)
+            qs[i / (NF * 16)][i % (NF * 16)] = reinterpret_cast<const f32x4*>(queries)[i];
+    }
     __syncthreads();
 
     const int lane = tid & 63;
@@ -647,7 +691,16 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select(
     rr_scan_geom G, const float* __restrict__ sims, const float* __restrict__ gmax,
     const uint32_t* __restrict__ smax, int pool, int64_t row_offset,
     int64_t* __restrict__ out_rows, float* __restrict__ out_scores, int32_t* __restrict__ dbg,
-    const int32_t* __restrict__ only_if, int n_total, int64_t sims_slice, int64_t gmax_slice, int64_t smax_slice) {
+    const int32_t* __restrict__ only_if, int n_total, int64_t sims_slice, int64_t gmax_slice, int64_t smax_slice,
+    const int32_t* __restrict__ qlist, int32_t* __restrict__ clear_flags) {
+    if (qlist) {
+        // scores of slot blockIdx.x belong to query qlist[1 + blockIdx.x] of the call (rr_scan_f32<.., LISTED>): its answer
+        // goes there and its flag comes down (the split-operand fallback behind this launch skips it)
+        if ((int)blockIdx.x >= qlist[0]) return;
+        const int qo = qlist[1 + blockIdx.x] - (int)blockIdx.x;
+        out_rows += (int64_t)qo * pool; out_scores += (int64_t)qo * pool; dbg += qo * 16;
+        if (threadIdx.x == 0) clear_flags[qo + (int)blockIdx.x] = 0;
+    }
     if (gridDim.y > 1) {
         // the sliced fallback (rr_dense_x3w_fallback_all): slice y = queries 64 y .. of the call, its own scratch
         const int y = blockIdx.y;
@@ -1192,7 +1245,7 @@ void rr_launch_select(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int
     const dim3 grid(slices > 1 ? RR_MFMA_MAXQ : nq, slices > 1 ? slices : 1);
     hipLaunchKernelGGL(rr_select, grid, dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
                        ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, only_if, nq, sims_slice,
-                       gmax_slice, smax_slice);
+                       gmax_slice, smax_slice, (const int32_t*)nullptr, (int32_t*)nullptr);
 }
 int rr_resident_waves(const void* kernel, int threads, int device) {
     int per_cu = 0, cus = 0;
@@ -1215,7 +1268,7 @@ static rr_scan_geom rr_launch_scan(rr_index* ix, const float* d_q, hipStream_t s
         G = rr_make_geom(ix, cap6);
         const int grid = (G.n_waves + 3) / 4;
         hipLaunchKernelGGL((rr_scan_f32<6, NB>), dim3(grid), dim3(RR_SCAN_THREADS), 0, st, mat, G, d_q,
-                           ix->d_sims, ix->d_gmax, ix->d_smax);
+                           ix->d_sims, ix->d_gmax, ix->d_smax, (const int32_t*)nullptr, 0, (int32_t*)nullptr);
     } else {
         if (!capg) capg = rr_resident_grid(rr_scan_f32_generic<NB>, ix->device);
         G = rr_make_geom(ix, capg);
@@ -1224,6 +1277,26 @@ static rr_scan_geom rr_launch_scan(rr_index* ix, const float* d_q, hipStream_t s
                            d_q, ix->d_sims, ix->d_gmax, ix->d_smax);
     }
     return G;
+}
+
+// The filter path's flagged queries (candidate lists overflowed: massive ties, a crowded cut), the first eight of a call:
+// the single-query scan's per-row chain over the whole matrix + the stored-score selection, bit for bit what a batch of
+// one returns; their flags come down, the rest (if any) go on to the split-operand pass.  fp32 storage, dim 384.
+int rr_dense_listed_fallback(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows, float* d_scores,
+                             int32_t* flags, hipStream_t st) {
+    static const bool off = getenv("RR_NO_CHAIN_FALLBACK") != nullptr;
+    if (off || ix->dtype != RR_DTYPE_F32 || ix->dim_pad != 384 || !ix->d_flag_list) return RR_OK;
+    static int cap = 0;
+    if (!cap) cap = rr_resident_grid(rr_scan_f32<6, 8, true>, ix->device);
+    rr_scan_geom G = rr_make_geom(ix, cap);
+    hipLaunchKernelGGL((rr_scan_f32<6, 8, true>), dim3((G.n_waves + 3) / 4), dim3(RR_SCAN_THREADS), 0, st,
+                       reinterpret_cast<const f32x4*>(ix->d_matrix), G, d_q, ix->d_sims, ix->d_gmax, ix->d_smax,
+                       (const int32_t*)flags, nq, ix->d_flag_list);
+    hipLaunchKernelGGL(rr_select, dim3(8), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax, ix->d_smax, pool,
+                       ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr, 8, (int64_t)0, (int64_t)0,
+                       (int64_t)0, (const int32_t*)ix->d_flag_list, flags);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
 }
 
 // Scan + select for up to 8 queries already on the device (padded to dim_pad).
@@ -1248,7 +1321,8 @@ static int rr_dense_chunk(rr_index* ix, const float* d_q, int nq, int pool, int6
         ix->timing_valid = true;
     }
     hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
-                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr, nq, (int64_t)0, (int64_t)0, (int64_t)0);
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr, nq, (int64_t)0, (int64_t)0, (int64_t)0,
+                       (const int32_t*)nullptr, (int32_t*)nullptr);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
@@ -1280,7 +1354,8 @@ static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool,
     ix->ring_head++;
     if (ix->ring_head - ix->ring_tail > rr_index::kRing) ix->ring_tail = ix->ring_head - rr_index::kRing;
     hipLaunchKernelGGL(rr_select, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, ix->d_sims, ix->d_gmax,
-                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr, nq, (int64_t)0, (int64_t)0, (int64_t)0);
+                       ix->d_smax, pool, ix->row_offset, d_rows, d_scores, ix->d_sel_trace, (const int32_t*)nullptr, nq, (int64_t)0, (int64_t)0, (int64_t)0,
+                       (const int32_t*)nullptr, (int32_t*)nullptr);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }

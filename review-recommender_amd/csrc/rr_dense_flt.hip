@@ -1404,8 +1404,13 @@ static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, 
                        X.mtiles, X.count, X.fb, X.sc, plane_rows, X.tau, X.eps);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st, floor != nullptr);
     RR_HIP_TRY(hipGetLastError());
-    // Flagged queries: the stored-score pass of the split-operand scan, 64 queries per slice of ONE pair of launches;
-    // every slice returns at once when no flag of its queries is up.
+    // Flagged queries: the first eight by the single-query chain (bit for bit a batch of one), the rest by the stored-score
+    // pass of the split-operand scan, 64 queries per slice of ONE pair of launches; every launch returns at once when no
+    // flag (of its queries) is up.
+    if (!ROWS_BF16) {
+        const int rc = rr_dense_listed_fallback(ix, d_q, nq, pool, d_rows, d_scores, X.fb, st);
+        if (rc != RR_OK) return rc;
+    }
     return rr_dense_x3w_fallback_all(ix, d_q, nq, pool, d_rows, d_scores, X.fb, st);
 }
 

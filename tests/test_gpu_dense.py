@@ -156,6 +156,8 @@ def test_filter_path_falls_back_per_query_on_massive_ties():
     assert np.all(scores[0] == scores[0][0])
     r1, s1 = ix.dense_topk(Q[5:6], 150)          # a query that stayed on the filter path
     assert np.array_equal(r1[0], rows[5]) and np.array_equal(s1[0], scores[5])
+    r0, s0 = ix.dense_topk(Q[0:1], 150)          # the flagged one: served by the single-query chain inside the batch too
+    assert np.array_equal(r0[0], rows[0]) and np.array_equal(s0[0].view(np.uint32), scores[0].view(np.uint32))
     ix.set_scan_mode(stored=True)
     rows1, sc1 = ix.dense_topk(Q, 150)
     ix.set_scan_mode(stored=False)
@@ -195,8 +197,32 @@ def test_filter_path_crowded_cut_still_exact():
     for i in range(len(Q)):
         # (fp32 itself reorders this crowd against float64: a wider tie band than elsewhere)
         assert_topk_matches(rows[i], scores[i], OD.sims_float64(V, Q[i]), 150, tie_eps=2e-6)
-        r1, s1 = ix.dense_topk(Q[i:i + 1], 150)
-        _same_up_to_rounding(r1, s1, rows[i:i + 1], scores[i:i + 1], atol=2e-6)   # (scores near 1: same-sign chains)
+        r1, s1 = ix.dense_topk(Q[i:i + 1], 150)          # bit for bit: the flagged query goes through the single-query chain
+        assert np.array_equal(r1[0], rows[i]) and np.array_equal(s1[0].view(np.uint32), scores[i].view(np.uint32))
+    ix.close()
+
+
+def test_more_than_eight_flagged_queries_are_split_between_the_chain_and_the_split_operand_pass():
+    # twelve queries tie on 20000 rows: the first eight flagged ones are served by the single-query chain (bit for bit a
+    # batch of one), the other four by the stored-score pass of the split-operand scan (equal to fp32 rounding); all exact
+    V = synth.unit_rows(200_000, 384, 91)
+    V[::10] = V[3]
+    Q = synth.unit_rows(40, 384, 93)
+    flagged = [1, 4, 5, 9, 12, 13, 20, 21, 30, 31, 38, 39]
+    Q[flagged] = V[3]
+    ix = ProductIndex(V)
+    rows, scores = ix.dense_topk(Q, 150)
+    want = sorted({3} | set(range(0, 10 * 150, 10)))[:150]
+    r1, s1 = ix.dense_topk(Q[1:2], 150)
+    for n, q in enumerate(flagged):
+        assert rows[q].tolist() == want
+        if n < 8:
+            assert np.array_equal(scores[q].view(np.uint32), s1[0].view(np.uint32))
+        else:
+            assert np.allclose(scores[q], s1[0], rtol=0, atol=1e-6)       # (scores near 1: a few fp32 ulps between the two arithmetics)
+    for q in (0, 2, 37):                         # neighbours that stayed on the filter path
+        rq, sq = ix.dense_topk(Q[q:q + 1], 150)
+        assert np.array_equal(rq[0], rows[q]) and np.array_equal(sq[0].view(np.uint32), scores[q].view(np.uint32))
     ix.close()
 
 

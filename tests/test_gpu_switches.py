@@ -149,10 +149,12 @@ from review_recommender_amd.index import ProductIndex
 V = synth.unit_rows(200_000, 384, 91)
 V[::10] = V[3]                                   # 20000 copies of row 3: a query equal to it overflows its candidate list
 Q = synth.unit_rows(200, 384, 92)
-Q[[0, 70, 199]] = V[3]                           # flagged queries in three of the four 64-query blocks
+flagged = [0, 1, 2, 3, 4, 5, 70, 71, 72, 73, 74, 75, 199]   # the first eight go to the single-query chain, the rest to the
+Q[flagged] = V[3]                                # split-operand pass: flagged queries in three of the four 64-query blocks
 ix = ProductIndex(V)
 rows, sims = ix.dense_topk(Q, 150)
-assert rows[70].tolist() == sorted({3} | set(range(0, 1500, 10)))[:150]
+for q in flagged:
+    assert rows[q].tolist() == sorted({3} | set(range(0, 1500, 10)))[:150]
 print("RESULT " + json.dumps([hashlib.sha256(rows.tobytes()).hexdigest(), hashlib.sha256(sims.tobytes()).hexdigest()]))
 """ % ROOT
 
