@@ -809,7 +809,9 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 // chunks are dealt out over the 24 MFMA slots of the chunk after it.
 #define CE_QKV_TOK 256
 #define CE_QKV_LDS(N) (2 * CE_FFN_CH * CE_W1_LD * 2 + (N) * 4 + 8 * 32 * 80)
-template <int DEPTH>
+// EXP (debug library only, RR_CE_PROJ_EXP): bit 0 = no output, bit 1 = no staging of the next chunks, bit 2 = no barrier
+// per chunk (timing only: the results are garbage); bit 3 = output rows stored with sc1 (correct results).
+template <int DEPTH, int EXP = 0>
 __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restrict__ hb, int M, const unsigned short* __restrict__ W,
                                                    const float* __restrict__ bias, int N, unsigned short* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ce_smem[];
@@ -826,9 +828,14 @@ __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restri
     // a chunk = 32 rows x 768 B = 1536 pieces of 16 B, three per thread
     u32x4 pw[3];
     const int nch = N / CE_FFN_CH;
+    // Workgroup w takes the chunks in the order rot, rot + 1, ... (mod nch): the chunks are independent output columns, so
+    // the order changes no bit of the result, and at any moment the CUs ask L2 for 36 different 24 KB pieces instead of all
+    // for the same one (r03 ablation: the staging of the next chunks was ~100 of the launch's 136 us)
+    const int rot = (int)((blockIdx.x * 7u) % (unsigned)nch);
+    auto chunk_of = [&](int k) { const int kk = k + rot; return kk >= nch ? kk - nch : kk; };
     auto load_w = [&](int k, int i) {
         const int id = tid + 512 * i;
-        pw[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)(k * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
+        pw[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)(chunk_of(k) * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
     };
     auto store_w = [&](int k, int i) {
         const int id = tid + 512 * i;
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restri
         f32x16 v;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(bs + k * CE_FFN_CH + 8 * g + 4 * hh);
+            const f32x4 q = *reinterpret_cast<const f32x4*>(bs + chunk_of(k) * CE_FFN_CH + 8 * g + 4 * hh);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * g + r] = q[r];
         }
@@ -874,7 +881,9 @@ __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restri
         const u32x4 v = *reinterpret_cast<const u32x4*>(tp + t * 80 + 16 * pc);
         int64_t row = row0 + t;
         row = row < rlast ? row : rlast;             // (lanes past M hold row M - 1 again: the same bytes)
-        *reinterpret_cast<u32x4*>(out + row * N + k * CE_FFN_CH + 8 * pc) = v;
+        u32x4* dst = reinterpret_cast<u32x4*>(out + row * N + chunk_of(k) * CE_FFN_CH + 8 * pc);
+        if (EXP & 8) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(v) : "memory");   // (A/B: rows that leave L2 at once)
+        else *dst = v;
     };
     for (int k = 0; k < nch; ++k) {
         const unsigned short* ap = wbuf + (k & 1) * CE_FFN_CH * CE_W1_LD + c * CE_W1_LD + 8 * hh;
@@ -889,13 +898,13 @@ __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restri
             if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
             // slots 1, 5, 9: chunk k + 1 registers -> LDS (its home held chunk k - 1, read before the last barrier);
             // slots 3, 7, 11: chunk k + 2 global -> registers; slots 13 .. 16 and 19, 21: the previous chunk's output
-            if (s == 1 || s == 5 || s == 9) store_w(k + 1, (s - 1) >> 2);
-            if (s == 3 || s == 7 || s == 11) load_w(kn, (s - 3) >> 2);
-            if (k > 0 && s >= 13 && s <= 16) put_lds(s - 13);
-            if (k > 0 && (s == 19 || s == 21)) put_rows(k - 1, (s - 19) >> 1);
+            if (!(EXP & 2) && (s == 1 || s == 5 || s == 9)) store_w(k + 1, (s - 1) >> 2);
+            if (!(EXP & 2) && (s == 3 || s == 7 || s == 11)) load_w(kn, (s - 3) >> 2);
+            if (!(EXP & 1) && k > 0 && s >= 13 && s <= 16) put_lds(s - 13);
+            if (!(EXP & 1) && k > 0 && (s == 19 || s == 21)) put_rows(k - 1, (s - 19) >> 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        lds_barrier();
+        if (!(EXP & 4)) lds_barrier();
         prev = acc;
     }
 #pragma unroll
@@ -1513,6 +1522,13 @@ static int ce_set_attributes(int device) {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
 #ifdef RR_DEBUG_HARNESS
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
+#endif
+#ifdef RR_DEBUG_HARNESS
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
 #endif
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * (CE_F32_KLD + CE_HD) * 4));
@@ -1624,8 +1640,20 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
             hipLaunchKernelGGL((ce_gemm<128, 384, 2, 4, CE_EPI_BIAS>), dim3(ce_grid(T, 128, 3 * CE_H / 384)), dim3(512), ldsP, st, ce->hb, L.wqkv,
                                L.bqkv, T, 3 * CE_H, CE_H, ce->qkv, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f);
         else
+        {
+#ifdef RR_DEBUG_HARNESS
+            static const int pe = getenv("RR_CE_PROJ_EXP") ? atoi(getenv("RR_CE_PROJ_EXP")) : 0;
+            const dim3 pg((unsigned)((T + CE_QKV_TOK - 1) / CE_QKV_TOK));
+            if (pe == 1) hipLaunchKernelGGL((ce_proj_ts<4, 1>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
+            else if (pe == 2) hipLaunchKernelGGL((ce_proj_ts<4, 2>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
+            else if (pe == 3) hipLaunchKernelGGL((ce_proj_ts<4, 3>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
+            else if (pe == 7) hipLaunchKernelGGL((ce_proj_ts<4, 7>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
+            else if (pe == 8) hipLaunchKernelGGL((ce_proj_ts<4, 8>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
+            else
+#endif
             hipLaunchKernelGGL((ce_proj_ts<4>), dim3((unsigned)((T + CE_QKV_TOK - 1) / CE_QKV_TOK)), dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T,
                                L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
+        }
         hipLaunchKernelGGL(ce_attention, dim3((unsigned)n_seqs, CE_HEADS), dim3(CE_ATT_THREADS), ce_attention_lds(smax_pad), st,
                            ce->qkv, d_cu_seqlens, ce->ctx, 0.17677669529663687f /* 1 / sqrt(32) */, smax_pad,
                            cls_tail ? ce->ctxc : (unsigned short*)nullptr);
