@@ -93,17 +93,19 @@ __device__ __forceinline__ void rr_finish_tile(const rr_scan_geom& G, int64_t ti
     }
 }
 
-// The (at most NB) first queries of a call whose flag is up: every wave works the list out for itself (four coalesced
-// loads + ballots), so that no launch stands between the flags and their readers.  Returns the count; slots past it
-// repeat the last query.
+// The queries of a call whose flag is up, if there are at most NB of them: every wave works the list out for itself (four
+// coalesced loads + ballots), so that no launch stands between the flags and their readers.  Returns the count -- 0 when
+// MORE than NB flags are up (a clustered corpus flags every query: a pass of this scan for eight of them would only add to
+// the split-operand passes the others need anyway); slots past the count repeat the last query.
 template <int NB>
 __device__ __forceinline__ int rr_flagged_list(const int32_t* __restrict__ flags, int nq, int lane, int (&list)[NB]) {
-    int n = 0;
+    int n = 0, total = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) list[b] = 0;
-    for (int i = 0; i < (nq + 63) / 64 && n < NB; ++i) {
+    for (int i = 0; i < (nq + 63) / 64; ++i) {
         const int q = 64 * i + lane;
         unsigned long long m = __ballot(q < nq && flags[q] != 0);
+        total += __builtin_popcountll(m);
         while (m && n < NB) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
@@ -113,14 +115,16 @@ __device__ __forceinline__ int rr_flagged_list(const int32_t* __restrict__ flags
             ++n;
         }
     }
+    if (total > NB) return 0;
 #pragma unroll
     for (int j = 1; j < NB; ++j)
         if (j >= n && n > 0) list[j] = list[j - 1];
     return n;
 }
 
-// LISTED: the queries are the first (at most NB) of `queries` whose flag is up (the filter path's flagged queries, served
-// by this kernel's per-row chain: bit for bit the single-query answer); nothing flagged -> every workgroup returns at once.
+// LISTED: the queries are those of `queries` whose flag is up, when there are at most NB of them (the filter path's flagged
+// queries, served by this kernel's per-row chain: bit for bit the single-query answer); nothing (or too much) flagged ->
+// every workgroup returns at once.
 template <int NF, int NB, bool LISTED = false>
 __global__ __launch_bounds__(RR_SCAN_THREADS, (NB <= 1 ? 4 : 2)) void rr_scan_f32(
     const f32x4* __restrict__ mat, rr_scan_geom G, const float* __restrict__ queries,  // NB x (NF*64)
@@ -1279,9 +1283,9 @@ static rr_scan_geom rr_launch_scan(rr_index* ix, const float* d_q, hipStream_t s
     return G;
 }
 
-// The filter path's flagged queries (candidate lists overflowed: massive ties, a crowded cut), the first eight of a call:
+// The filter path's flagged queries (candidate lists overflowed: massive ties, a crowded cut), when a call has at most eight:
 // the single-query scan's per-row chain over the whole matrix + the stored-score selection, bit for bit what a batch of
-// one returns; their flags come down, the rest (if any) go on to the split-operand pass.  fp32 storage, dim 384.
+// one returns; their flags come down.  More than eight: all of them go on to the split-operand pass.  fp32 storage, dim 384.
 int rr_dense_listed_fallback(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows, float* d_scores,
                              int32_t* flags, hipStream_t st) {
     static const bool off = getenv("RR_NO_CHAIN_FALLBACK") != nullptr;

@@ -1404,7 +1404,7 @@ static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, 
                        X.mtiles, X.count, X.fb, X.sc, plane_rows, X.tau, X.eps);
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st, floor != nullptr);
     RR_HIP_TRY(hipGetLastError());
-    // Flagged queries: the first eight by the single-query chain (bit for bit a batch of one), the rest by the stored-score
+    // Flagged queries: at most eight in the call -> the single-query chain (bit for bit a batch of one); more -> the stored-score
     // pass of the split-operand scan, 64 queries per slice of ONE pair of launches; every launch returns at once when no
     // flag (of its queries) is up.
     if (!ROWS_BF16) {

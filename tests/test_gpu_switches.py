@@ -149,8 +149,8 @@ from review_recommender_amd.index import ProductIndex
 V = synth.unit_rows(200_000, 384, 91)
 V[::10] = V[3]                                   # 20000 copies of row 3: a query equal to it overflows its candidate list
 Q = synth.unit_rows(200, 384, 92)
-flagged = [0, 1, 2, 3, 4, 5, 70, 71, 72, 73, 74, 75, 199]   # the first eight go to the single-query chain, the rest to the
-Q[flagged] = V[3]                                # split-operand pass: flagged queries in three of the four 64-query blocks
+flagged = [0, 1, 2, 3, 4, 5, 70, 71, 72, 73, 74, 75, 199]   # more than eight: all of them go to the split-operand pass;
+Q[flagged] = V[3]                                # flagged queries in three of the four 64-query blocks
 ix = ProductIndex(V)
 rows, sims = ix.dense_topk(Q, 150)
 for q in flagged:
