@@ -381,8 +381,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
 // The 6 KB-per-token intermediate never leaves the CU, the whole FFN is one launch, and the LayerNorm statistics of a
 // token are sums over the registers of one lane pair (lane, lane ^ 32): no cross-wave reduction.
 // Workgroup = 4 waves x 32 tokens, one wave per SIMD (hb fragments 96 + out^T accumulators 192 registers per lane); W1 / W2
-// chunks (24 KB each) stream L2 -> registers -> LDS, double-buffered, one barrier per chunk; per chunk and wave 48 MFMAs
-// against 48 ds_read_b128.
+// chunks (24 KB each) stream L2 -> registers -> LDS, double-buffered, one barrier per iteration; per iteration and wave 48
+// MFMAs against 48 ds_read_b128.  Round 3: the iteration is one sequence of 48 MFMA slots (the second product of the
+// previous chunk, then the first product of the next) with the GELU -- Phi by table interpolation --, the staging stores
+// and loads dealt out over the slots; the residual row is the accumulators' start; the rows leave through LDS in whole
+// lines; OPROJ puts the attention output projection + first LayerNorm in front.  
 #define CE_FFN_TOK 128          // tokens per workgroup
 #define CE_FFN_CH 32            // intermediate features per chunk
 #define CE_W1_LD (CE_H + 8)     // LDS row of a W1 chunk: 384 bf16 + 16 B pad
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N == 4 ? 2
 // forward: <4, false> 6.26 ms, <8, false> 6.38 ms, <4, true> 6.38 ms -- neither LDS depth nor L2 hot-spotting is what
 // bounds the kernel (a single wave per SIMD issues its VALU, LDS and MFMA work in order); only <4, false> is built.
 #ifdef RR_DEBUG_HARNESS
-// in-kernel phase clocks of ce_ffn_fused (tools/k5_stamps.py): [wave 0 of workgroups 0 and 600][8] cycle sums
+// in-kernel phase clocks of ce_ffn_fused (tools/k5_stamps.py): [wave 0 of workgroups 0 and 600][10] cycle sums
 __device__ unsigned long long ce_dbg_ffn[2][10];
 #define CE_STAMP(slot) do { const unsigned long long t_ = clock64(); dbg_t[slot] += t_ - dbg_last; dbg_last = t_; } while (0)
 #else
@@ -424,8 +427,7 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     const int c = lane & 31, hh = lane >> 5;
     const int64_t tok0 = (int64_t)blockIdx.x * CE_FFN_TOK + wave * 32;
     int64_t tok = tok0 + c;
-    const bool live = tok < M;
-    tok = live ? tok : M - 1;
+    tok = tok < M ? tok : M - 1;                 // (lanes past M work on row M - 1 again and write the same bytes to it)
 
     // the tokens' rows as B fragments: lane (c, hh), K-step s holds hb[tok][16 s + 8 hh .. + 7]
     bf16x8 hf[24];
@@ -472,13 +474,6 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         for (int i = 0; i < 6; ++i) {
             const int id = tid + 256 * i;
             *reinterpret_cast<u32x4*>(buf + (id / 48) * CE_W1_LD + (id % 48) * 8) = pw[i];
-        }
-    };
-    auto store_w2 = [&](unsigned short* buf) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int id = tid + 256 * i;
-            *reinterpret_cast<u32x4*>(buf + (id >> 2) * CE_W2_LD + (id & 3) * 8) = pw2[i];
         }
     };
     auto lds_barrier = [&]() {
