@@ -644,16 +644,24 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         const int k = e >> 1, i = e & 1;
         float x = xc[e];
         float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(x, CE_GELU_N / (2.f * CE_GELU_R), CE_GELU_N / 2.f), 0.f, 511.99997f);
-        unsigned int off = (unsigned int)t * 8u;
+        const unsigned int idx = (unsigned int)t;
         float f = __builtin_amdgcn_fractf(t);
-        asm volatile("" : "+v"(x), "+v"(f), "+v"(off));
+        asm volatile("" : "+v"(x), "+v"(f));
         gx[k & 1][i] = x;
         gf[k & 1][i] = f;
-        gt[k & 1][i] = *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const unsigned char*>(gtab) + off);
+        gt[k & 1][i] = reinterpret_cast<const f32x2_t*>(gtab)[idx];
     };
     auto gelu_finish = [&](int k) {                  // pair k -> xbw
-        const float y0 = gx[k & 1][0] * __builtin_fmaf(gf[k & 1][0], gt[k & 1][0][1], gt[k & 1][0][0]);
-        const float y1 = gx[k & 1][1] * __builtin_fmaf(gf[k & 1][1], gt[k & 1][1][1], gt[k & 1][1][0]);
+        // (one value at a time, each pinned: paired up by the vectoriser they become v_pk_fma / v_pk_mul -- two plain
+        //  instructions' worth each on this chip -- plus the moves that line their operands up)
+        float p0 = __builtin_fmaf(gf[k & 1][0], gt[k & 1][0][1], gt[k & 1][0][0]);
+        asm volatile("" : "+v"(p0));
+        float p1 = __builtin_fmaf(gf[k & 1][1], gt[k & 1][1][1], gt[k & 1][1][0]);
+        asm volatile("" : "+v"(p1));
+        float y0 = gx[k & 1][0] * p0;
+        asm volatile("" : "+v"(y0));
+        float y1 = gx[k & 1][1] * p1;
+        asm volatile("" : "+v"(y1));
         unsigned int pk = __builtin_bit_cast(unsigned int, (bf16x2_t){(__bf16)y0, (__bf16)y1});
         asm volatile("" : "+v"(pk));
         xbw[k >> 2][k & 3] = pk;
@@ -679,14 +687,19 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         // nobody reads.)  Slot j carries a GELU piece when j % 3 == 0 (look-up of value j / 3), j == 6 k + 7 (finish of pair
         // k, its gathers four slots old) and j == 47; the other 24 slots carry staging piece 0 .. 23.
         const int cw1 = chunk_of(ch + 3 < NCH ? ch + 3 : NCH - 1), cw2 = chunk_of(ch + 1 < NCH ? ch + 1 : NCH - 1);
+        // (global addresses = a wave-uniform base per piece + ONE per-lane 32-bit offset: a W1 chunk is 24 KB of contiguous
+        //  rows, piece id at byte 16 id; W2p piece id is row (id >> 2) = (tid >> 2) + 64 i, 16-byte column id & 3)
+        const unsigned char* g1 = reinterpret_cast<const unsigned char*>(W1) + (size_t)cw1 * (CE_FFN_CH * CE_H * 2);
+        const unsigned char* g2 = reinterpret_cast<const unsigned char*>(W2p) + (size_t)cw2 * (CE_FFN_CH * 2);
+        const unsigned int l1 = 16u * tid, l2 = (unsigned int)(tid >> 2) * (CE_FFN * 2) + 16u * (tid & 3);
         auto staging = [&](int n) {
             const int i = (n % 12) >> 1, id = tid + 256 * i;
             if (n < 12) {
                 if ((n & 1) == 0) *reinterpret_cast<u32x4*>(w1_of(ch + 2) + (id / 48) * CE_W1_LD + (id % 48) * 8) = pw[i];
-                else pw[i] = *reinterpret_cast<const u32x4*>(W1 + (int64_t)(cw1 * CE_FFN_CH + id / 48) * CE_H + (id % 48) * 8);
+                else pw[i] = *reinterpret_cast<const u32x4*>(g1 + (size_t)i * 4096 + l1);
             } else {
                 if ((n & 1) == 0) *reinterpret_cast<u32x4*>(w2_of(ch) + (id >> 2) * CE_W2_LD + (id & 3) * 8) = pw2[i];
-                else pw2[i] = *reinterpret_cast<const u32x4*>(W2p + (int64_t)(id >> 2) * CE_FFN + cw2 * CE_FFN_CH + (id & 3) * 8);
+                else pw2[i] = *reinterpret_cast<const u32x4*>(g2 + (size_t)i * (64 * CE_FFN * 2) + l2);
             }
         };
         CE_STAMP(1);                                 // top of the iteration
