@@ -818,7 +818,8 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
 #define CE_QKV_TOK 256
 #define CE_QKV_LDS(N) (2 * CE_FFN_CH * CE_W1_LD * 2 + (N) * 4 + 8 * 32 * 80)
 // EXP (debug library only, RR_CE_PROJ_EXP): bit 0 = no output, bit 1 = no staging of the next chunks, bit 2 = no barrier
-// per chunk (timing only: the results are garbage); bit 3 = output rows stored with sc1 (correct results).
+// per chunk (timing only: the results are garbage); bit 3 = output rows stored with sc1 (correct results); bit 4 = the staging
+// loads without their LDS stores, bit 5 = the LDS stores without the loads (garbage).
 template <int DEPTH, int EXP = 0>
 __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restrict__ hb, int M, const unsigned short* __restrict__ W,
                                                    const float* __restrict__ bias, int N, unsigned short* __restrict__ out) {
@@ -906,8 +907,11 @@ __global__ __launch_bounds__(512) void ce_proj_ts(const unsigned short* __restri
             if (s + DEPTH < 24) af[s % DEPTH] = *reinterpret_cast<const bf16x8*>(ap + 16 * (s + DEPTH));
             // slots 1, 5, 9: chunk k + 1 registers -> LDS (its home held chunk k - 1, read before the last barrier);
             // slots 3, 7, 11: chunk k + 2 global -> registers; slots 13 .. 16 and 19, 21: the previous chunk's output
-            if (!(EXP & 2) && (s == 1 || s == 5 || s == 9)) store_w(k + 1, (s - 1) >> 2);
-            if (!(EXP & 2) && (s == 3 || s == 7 || s == 11)) load_w(kn, (s - 3) >> 2);
+            if (!(EXP & 2) && (s == 1 || s == 5 || s == 9)) {
+                if (EXP & 16) asm volatile("" :: "v"(pw[(s - 1) >> 2]));          // (ablation: the loads stay, the LDS stores go)
+                else store_w(k + 1, (s - 1) >> 2);
+            }
+            if (!(EXP & 2) && !(EXP & 32) && (s == 3 || s == 7 || s == 11)) load_w(kn, (s - 3) >> 2);
             if (!(EXP & 1) && k > 0 && s >= 13 && s <= 16) put_lds(s - 13);
             if (!(EXP & 1) && k > 0 && (s == 19 || s == 21)) put_rows(k - 1, (s - 19) >> 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -1535,6 +1539,8 @@ static int ce_set_attributes(int device) {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
 #endif
 #ifdef RR_DEBUG_HARNESS
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
@@ -1657,6 +1663,8 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
             else if (pe == 3) hipLaunchKernelGGL((ce_proj_ts<4, 3>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
             else if (pe == 7) hipLaunchKernelGGL((ce_proj_ts<4, 7>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
             else if (pe == 8) hipLaunchKernelGGL((ce_proj_ts<4, 8>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
+            else if (pe == 16) hipLaunchKernelGGL((ce_proj_ts<4, 16>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
+            else if (pe == 32) hipLaunchKernelGGL((ce_proj_ts<4, 32>), pg, dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T, L.wqkv, L.bqkv, 3 * CE_H, ce->qkv);
             else
 #endif
             hipLaunchKernelGGL((ce_proj_ts<4>), dim3((unsigned)((T + CE_QKV_TOK - 1) / CE_QKV_TOK)), dim3(512), CE_QKV_LDS(3 * CE_H), st, ce->hb, (int)T,
