@@ -412,7 +412,8 @@ __device__ unsigned long long ce_dbg_ffn[2][10];
 // normalised rows stay in the accumulators as the second LayerNorm's residual and become the FFN's B fragments by one
 // v_permlane32_swap per two dwords -- the [T][384] fp32 + bf16 round trip through HBM between the two kernels, the second
 // kernel's row loads and the first one's row stores are gone.
-template <int DEPTH, bool STAGGER, bool OPROJ>
+// (NOSTORE: debug library only, RR_CE_FFN_NOSTORE=1 -- the staging loads without their LDS stores in the main loop; garbage results)
+template <int DEPTH, bool STAGGER, bool OPROJ, bool NOSTORE = false>
 __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
     unsigned short* __restrict__ hb, float* __restrict__ h32, int M,
     const unsigned short* __restrict__ W1, const float* __restrict__ b1,       // [1536][384], [1536]
@@ -695,11 +696,15 @@ __global__ __launch_bounds__(256, 1) void ce_ffn_fused(
         auto staging = [&](int n) {
             const int i = (n % 12) >> 1, id = tid + 256 * i;
             if (n < 12) {
-                if ((n & 1) == 0) *reinterpret_cast<u32x4*>(w1_of(ch + 2) + (id / 48) * CE_W1_LD + (id % 48) * 8) = pw[i];
-                else pw[i] = *reinterpret_cast<const u32x4*>(g1 + (size_t)i * 4096 + l1);
+                if ((n & 1) == 0) {
+                    if (NOSTORE) asm volatile("" :: "v"(pw[i]));
+                    else *reinterpret_cast<u32x4*>(w1_of(ch + 2) + (id / 48) * CE_W1_LD + (id % 48) * 8) = pw[i];
+                } else pw[i] = *reinterpret_cast<const u32x4*>(g1 + (size_t)i * 4096 + l1);
             } else {
-                if ((n & 1) == 0) *reinterpret_cast<u32x4*>(w2_of(ch) + (id >> 2) * CE_W2_LD + (id & 3) * 8) = pw2[i];
-                else pw2[i] = *reinterpret_cast<const u32x4*>(g2 + (size_t)i * (64 * CE_FFN * 2) + l2);
+                if ((n & 1) == 0) {
+                    if (NOSTORE) asm volatile("" :: "v"(pw2[i]));
+                    else *reinterpret_cast<u32x4*>(w2_of(ch) + (id >> 2) * CE_W2_LD + (id & 3) * 8) = pw2[i];
+                } else pw2[i] = *reinterpret_cast<const u32x4*>(g2 + (size_t)i * (64 * CE_FFN * 2) + l2);
             }
         };
         CE_STAMP(1);                                 // top of the iteration
@@ -1532,6 +1537,9 @@ static int ce_set_attributes(int device) {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ce_attention_lds(512)));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
+#ifdef RR_DEBUG_HARNESS
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<4, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
+#endif
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
 #ifdef RR_DEBUG_HARNESS
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_proj_ts<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_QKV_LDS(3 * CE_H)));
@@ -1681,6 +1689,13 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
         if (oproj_fused) {
             // attention output projection + residual + LayerNorm + FFN + residual + LayerNorm: one launch
             const dim3 fg((unsigned)((Mr + CE_FFN_TOK - 1) / CE_FFN_TOK));
+#ifdef RR_DEBUG_HARNESS
+            static const bool nostore = getenv("RR_CE_FFN_NOSTORE") != nullptr;
+            if (nostore) hipLaunchKernelGGL((ce_ffn_fused<4, false, true, true>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
+                               L.ln2_b, ce->cfg.ln_eps, ce->gelu_tab, (const unsigned short*)rctx, (const unsigned short*)L.wo, (const float*)L.bo,
+                               (const float*)L.ln1_g, (const float*)L.ln1_b);
+            else
+#endif
             hipLaunchKernelGGL((ce_ffn_fused<4, false, true>), fg, dim3(256), ldsF, st, rb, r32, Mr, L.w1, L.b1, L.w2p, L.b2, L.ln2_g,
                                L.ln2_b, ce->cfg.ln_eps, ce->gelu_tab, (const unsigned short*)rctx, (const unsigned short*)L.wo, (const float*)L.bo,
                                (const float*)L.ln1_g, (const float*)L.ln1_b);
