@@ -1117,6 +1117,109 @@ typedef float f32x16r __attribute__((ext_vector_type(16)));
 // the operands).  K % 16 == 0.  MFMA operands: A lane l = row (l & 31), k = l >> 5; B lane l = column (l & 31), k = l >> 5; C register
 // 4 g + i = row 8 g + 4 (l >> 5) + i, column l & 31.
 #define CE_F32_LD 132
+// fp32 GEMM on the bf16 matrix cores by operand splitting (the arithmetic of the exact K1a' scans, csrc/rr_x3.h): every fp32
+// operand x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (the subtractions are exact, the
+// three terms carry 24 bits), and a product keeps the six term pairs down to 2^-16 of it: hi*hi, hi*mid, mid*hi, hi*lo,
+// mid*mid, lo*hi -- what is dropped is below 2^-23 of the product, the rounding of one fp32 multiply; accumulation in fp32 in
+// the MFMA.  Six v_mfma_f32_32x32x16_bf16 per 16 k instead of eight v_mfma_f32_32x32x2_f32: 2.6 x the matrix rate at peak.
+// Same tile as ce_gemm_f32 (128 x 128 per workgroup, four waves of 2 x 2 MFMA blocks); a thread's eight consecutive k of one
+// row are exactly one lane's fragment: split in registers, one 16-byte LDS store per term, conflict-free 16-byte reads.
+template <bool GELU>
+__global__ __launch_bounds__(256) void ce_gemm_x3(const float* __restrict__ A, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, int M, int N, int K,
+                                                  float* __restrict__ out) {
+    // (K tiles of 32 -- two k-steps per LDS fill -- measured slower: 172 registers, one wave per SIMD fewer)
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * 2 * 128 * 8], Ws[3 * 2 * 128 * 8];   // [term][k half][row][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int srow = tid >> 1, skq = tid & 1;                 // staging: row of the tile, k half (8 consecutive k)
+    int arow = m0 + srow;
+    arow = arow < M ? arow : M - 1;                           // (rows past the end: clamped loads, masked stores)
+    const float* ap = A + (int64_t)arow * K + 8 * skq;
+    const float* wp = W + (int64_t)(n0 + srow) * K + 8 * skq;
+    f32x16r acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int r = lane & 31, kh = lane >> 5;
+    f32x4 av[2], wv[2];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        av[h2] = *reinterpret_cast<const f32x4*>(ap + 4 * h2);
+        wv[h2] = *reinterpret_cast<const f32x4*>(wp + 4 * h2);
+    }
+    auto split_store = [&](const f32x4 (&v)[2], unsigned short* dst) {       // eight fp32 -> three bf16x8 terms
+        bf16x8 t0, t1, t2;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = v[h2][e];
+                const __bf16 hi = (__bf16)x;
+                const float r1 = x - (float)hi;
+                const __bf16 mid = (__bf16)r1;
+                const float r2 = r1 - (float)mid;
+                t0[4 * h2 + e] = hi; t1[4 * h2 + e] = mid; t2[4 * h2 + e] = (__bf16)r2;
+            }
+        *reinterpret_cast<bf16x8*>(dst + ((0 * 2 + skq) * 128 + srow) * 8) = t0;
+        *reinterpret_cast<bf16x8*>(dst + ((1 * 2 + skq) * 128 + srow) * 8) = t1;
+        *reinterpret_cast<bf16x8*>(dst + ((2 * 2 + skq) * 128 + srow) * 8) = t2;
+    };
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        __syncthreads();                                      // the previous tile has been read
+        split_store(av, As);
+        split_store(wv, Ws);
+        __syncthreads();
+        if (k0 + 16 < K) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                av[h2] = *reinterpret_cast<const f32x4*>(ap + k0 + 16 + 4 * h2);
+                wv[h2] = *reinterpret_cast<const f32x4*>(wp + k0 + 16 + 4 * h2);
+            }
+        }
+        bf16x8 a[3][2], b[3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[t][i] = *reinterpret_cast<const bf16x8*>(As + ((t * 2 + kh) * 128 + wm + 32 * i + r) * 8);
+                b[t][i] = *reinterpret_cast<const bf16x8*>(Ws + ((t * 2 + kh) * 128 + wn + 32 * i + r) * 8);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                // smallest terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + r;
+            const float bv = bias[col];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm + 32 * i + 8 * (e >> 2) + 4 * kh + (e & 3);
+                if (row < M) {
+                    float x = acc[i][j][e] + bv;
+                    if (GELU) x = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));      // gelu(x) = x Phi(x), erf form (HF "gelu")
+                    out[(int64_t)row * N + col] = x;
+                }
+            }
+        }
+}
+
 template <bool GELU>
 __global__ __launch_bounds__(256) void ce_gemm_f32(const float* __restrict__ A, const float* __restrict__ W,
                                                    const float* __restrict__ bias, int M, int N, int K,
@@ -1583,17 +1686,25 @@ static int ce_forward_f32(rr_ce* ce, const int32_t* d_token_ids, const int32_t* 
                        ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type, ce->eln_g, ce->eln_b,
                        ce->cfg.ln_eps, ce->h32, ce->hb);
     const unsigned mt = (unsigned)((T + 127) / 128), ln_blocks = (unsigned)((T + 3) / 4);
+    static const bool f32_x3 = getenv("RR_CE_F32_MFMA") == nullptr;      // (RR_CE_F32_MFMA=1, A/B: the four GEMMs on v_mfma_f32_32x32x2_f32 instead of by operand splitting)
     const size_t att_lds = (size_t)((max_len + 31) & ~31) * (CE_F32_KLD + CE_HD) * 4;
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
-        hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(3 * CE_H / 128, mt), dim3(256), 0, st, ce->h32, L.wqkv32, L.bqkv, T, 3 * CE_H, CE_H, ce->qkv32);
+        if (f32_x3) hipLaunchKernelGGL((ce_gemm_x3<false>), dim3(3 * CE_H / 128, mt), dim3(256), 0, st, ce->h32, L.wqkv32, L.bqkv, T, 3 * CE_H, CE_H, ce->qkv32);
+        else hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(3 * CE_H / 128, mt), dim3(256), 0, st, ce->h32, L.wqkv32, L.bqkv, T, 3 * CE_H, CE_H, ce->qkv32);
         hipLaunchKernelGGL(ce_attention_f32, dim3((unsigned)n_seqs, CE_HEADS), dim3(256), att_lds, st, ce->qkv32, d_cu_seqlens, ce->y32,
                            0.17677669529663687f /* 1 / sqrt(32) */);
         // (y32 holds the context; the projection's output goes to the first T x 384 floats of inter32)
-        hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->y32, L.wo32, L.bo, T, CE_H, CE_H, ce->inter32);
+        if (f32_x3) hipLaunchKernelGGL((ce_gemm_x3<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->y32, L.wo32, L.bo, T, CE_H, CE_H, ce->inter32);
+        else hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->y32, L.wo32, L.bo, T, CE_H, CE_H, ce->inter32);
         hipLaunchKernelGGL(ce_add_ln_f32, dim3(ln_blocks), dim3(256), 0, st, ce->inter32, ce->h32, T, L.ln1_g, L.ln1_b, ce->cfg.ln_eps);
-        hipLaunchKernelGGL((ce_gemm_f32<true>), dim3(CE_FFN / 128, mt), dim3(256), 0, st, ce->h32, L.w1_32, L.b1, T, CE_FFN, CE_H, ce->inter32);
-        hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->inter32, L.w2_32, L.b2, T, CE_H, CE_FFN, ce->y32);
+        if (f32_x3) {
+            hipLaunchKernelGGL((ce_gemm_x3<true>), dim3(CE_FFN / 128, mt), dim3(256), 0, st, ce->h32, L.w1_32, L.b1, T, CE_FFN, CE_H, ce->inter32);
+            hipLaunchKernelGGL((ce_gemm_x3<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->inter32, L.w2_32, L.b2, T, CE_H, CE_FFN, ce->y32);
+        } else {
+            hipLaunchKernelGGL((ce_gemm_f32<true>), dim3(CE_FFN / 128, mt), dim3(256), 0, st, ce->h32, L.w1_32, L.b1, T, CE_FFN, CE_H, ce->inter32);
+            hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->inter32, L.w2_32, L.b2, T, CE_H, CE_FFN, ce->y32);
+        }
         hipLaunchKernelGGL(ce_add_ln_f32, dim3(ln_blocks), dim3(256), 0, st, ce->y32, ce->h32, T, L.ln2_g, L.ln2_b, ce->cfg.ln_eps);
     }
     if (mode == RR_CE_OUT_HIDDEN)

@@ -329,3 +329,20 @@ def test_bf16_path_switches_stay_inside_the_bf16_bar(ce_world, switch):
     got = np.array([float(v) for v in [l for l in p.stdout.splitlines() if l.startswith("LOGITS ")][-1].split()[1:]], dtype=np.float32)
     assert np.abs(got - fx["logits"]).max() < LOGIT_TOL
     assert np.abs(got - ce.predict_ids(split(fx))).max() < LOGIT_TOL
+
+
+def test_fp32_mode_on_the_fp32_input_matrix_instruction_meets_the_same_bar(ce_world_f32):
+    """The fp32 mode's GEMMs run by operand splitting on the bf16 matrix cores (three bf16 terms per operand, six products:
+    exact to the rounding of one fp32 multiply); RR_CE_F32_MFMA=1 runs them on v_mfma_f32_32x32x2_f32 instead.  Both forms
+    are held to the 1e-5 bar and agree with each other inside it."""
+    import os
+    import subprocess
+    import sys
+    fx, sd, ce = ce_world_f32
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = (K5_SWITCH_CHILD % (root, str(GOLDEN / "k5_cross_encoder.npz"))).replace('precision="bf16"', 'precision="fp32"')
+    p = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, RR_CE_F32_MFMA="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = np.array([float(v) for v in [l for l in p.stdout.splitlines() if l.startswith("LOGITS ")][-1].split()[1:]], dtype=np.float32)
+    assert np.abs(got - fx["logits"]).max() < F32_LOGIT_TOL
+    assert np.abs(got - ce.predict_ids(split(fx))).max() < F32_LOGIT_TOL
