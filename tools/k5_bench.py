@@ -19,7 +19,9 @@ def main():
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
-                    help="bf16 = the fast path (roofline: bf16 MFMA); fp32 = reference precision (fp32-input MFMA, 157 TF/s peak)")
+                    help="bf16 = the fast path (roofline: bf16 MFMA); fp32 = reference precision: fp32 FLOPs of the model against the "
+                         "fp32-input MFMA peak (157 TF/s) -- the yardstick only: its GEMMs run as six bf16 MFMA products per fp32 "
+                         "product (RR_CE_F32_MFMA=1 puts them on the fp32-input instruction)")
     a = ap.parse_args()
     from review_recommender_amd import synth
     from review_recommender_amd.cross_encoder import CrossEncoder
