@@ -1350,6 +1350,7 @@ __global__ __launch_bounds__(256) void ce_attention_f32(const float* __restrict_
     }
     __syncthreads();
     const int c = lane & 31, h = lane >> 5;
+    const float scale2 = scale * 1.4426950408889634f;        // the softmax in base 2: no range reduction per probability
     for (int q0 = 32 * wave; q0 < S; q0 += 128) {
         int qrow = q0 + c;
         qrow = qrow < S ? qrow : S - 1;                       // (lanes past the sequence: a valid row, never stored)
@@ -1372,13 +1373,13 @@ __global__ __launch_bounds__(256) void ce_attention_f32(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = j0 + 8 * (e >> 2) + 4 * h + (e & 3);
-                const float v = key < S ? sT[e] * scale : -INFINITY;
+                const float v = key < S ? sT[e] * scale2 : -INFINITY;     // scores in units of log2 e: p = exp2(v - max)
                 sT[e] = v;
                 cm = fmaxf(cm, v);
             }
             cm = fmaxf(cm, __shfl_xor(cm, 32, 64));           // the query's other 16 keys of this tile
             if (cm > mx) {                                    // (per lane: a query's two lanes decide alike)
-                const float r = expf(mx - cm);                // first tile: exp(-inf) = 0 on zero sums
+                const float r = __builtin_amdgcn_exp2f(mx - cm);     // first tile: exp2(-inf) = 0 on zero sums
                 l *= r;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[e] *= r;
@@ -1386,7 +1387,7 @@ __global__ __launch_bounds__(256) void ce_attention_f32(const float* __restrict_
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pe = expf(sT[e] - mx);            // masked keys: exp(-inf) = 0
+                const float pe = __builtin_amdgcn_exp2f(sT[e] - mx);      // masked keys: exp2(-inf) = 0 (v_exp_f32: 1 ulp)
                 sT[e] = pe;
                 l += pe;
             }
