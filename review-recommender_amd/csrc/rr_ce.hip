@@ -1370,13 +1370,18 @@ __global__ __launch_bounds__(256) void ce_attention_f32(const float* __restrict_
 #pragma unroll
             for (int st = 0; st < 16; ++st) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * st], qreg[st], sT, 0, 0, 0);
             float cm = -INFINITY;
+            if (j0 + 32 > S) {                                // only the last tile holds padding keys
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = j0 + 8 * (e >> 2) + 4 * h + (e & 3);
-                const float v = key < S ? sT[e] * scale2 : -INFINITY;     // scores in units of log2 e: p = exp2(v - max)
-                sT[e] = v;
-                cm = fmaxf(cm, v);
+                for (int e = 0; e < 16; ++e) {
+                    const int key = j0 + 8 * (e >> 2) + 4 * h + (e & 3);
+                    sT[e] = key < S ? sT[e] * scale2 : -INFINITY;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sT[e] *= scale2;             // scores in units of log2 e: p = exp2(v - max)
             }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cm = fmaxf(cm, sT[e]);
             cm = fmaxf(cm, __shfl_xor(cm, 32, 64));           // the query's other 16 keys of this tile
             if (cm > mx) {                                    // (per lane: a query's two lanes decide alike)
                 const float r = __builtin_amdgcn_exp2f(mx - cm);     // first tile: exp2(-inf) = 0 on zero sums
