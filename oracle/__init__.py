@@ -5,7 +5,8 @@ algorithm for the path SURVEY.md section 8 names (dense cosine top-k -> BM25 at 
 candidate pool -> priors / trust / gate -> weighted blend -> top-k).  Each
 function cites the reference file:line it follows.
 
-Rules (enforced by tests/test_no_oracle_in_product.py):
+Rules (enforced by tests/test_abi_and_layout.py::test_product_never_imports_the_oracle and
+::test_bench_uses_the_oracle_only_in_the_cpu_baseline_leg):
   * only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
     ``bench.py`` may import anything from here;
   * the product package (``review-recommender_amd/``) never imports it and has
@@ -25,9 +26,23 @@ Pinning status
     hand-computed known answers on the reference's own 3-doc fixture corpus,
     tests/conftest.py:90-100).
   * ``oracle.pipeline`` restates ``run_search`` (app/app_product_search.py:
-    245-317) and the CLI ``search`` (app/test.py:228-342).  Those modules
-    cannot be imported here (streamlit / hub fetches), and the reference's
-    tests pin no fused score  ->  **pipeline: parity unpinned beyond its
-    pinned primitives**; it is a line-by-line restatement using the same
-    numpy expressions so numpy's own dtype rules decide every rounding.
+    245-317) and the CLI ``search`` (app/test.py:228-342).
+      - cli flavour: PINNED BY A RUN OF app/test.py.  That module imports in
+        the build container with numpy + pandas only (its heavy imports sit
+        inside the three ``_load_*`` hooks, app/test.py:91-104);
+        tests/golden/make_cli_golden.py stubs those hooks the way the
+        reference's integration test does (tests/test_integration.py:41-48),
+        runs ``search(args)`` itself on seeded data/processed/* artefacts and
+        commits the JSON it writes (tests/golden/cli_search.json, 47 cases) plus
+        I/O of its helper functions (cli_helpers.json).  The oracle reproduces
+        every file exactly (tests/test_cli_golden.py).  The BM25 arithmetic
+        inside those runs is ``oracle.bm25`` (stubbed for the absent rank_bm25)
+        and so stays unpinned; everything around it is the reference's code.
+      - app flavour: the module cannot be imported (``import streamlit`` and
+        ``st.set_page_config`` at module level, app/app_product_search.py:9,30;
+        streamlit is not installed), and the reference's tests pin no fused
+        score  ->  **app flavour: parity unpinned beyond its pinned primitives
+        and beyond the statements it shares with the pinned cli flavour**
+        (it differs from it by the pool floor 150, the trust factor, the
+        sku-dict BM25 gather and the float32 cast of an empty min-max input).
 """

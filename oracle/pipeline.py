@@ -13,9 +13,14 @@ The same numpy / pandas expressions are used as in the reference so that every
 dtype promotion (float32 weak-scalar products, the float64 ``_prior`` column,
 the float64 ``_rerank`` column when rerank_k == 0) is decided by numpy itself.
 
-**Parity unpinned beyond the primitives**: neither module can be imported in
-this image (streamlit absent; hub fetches), and the reference's tests pin no
-fused value.
+Pinning: the **cli flavour is pinned by a run of the reference's own app/test.py**
+(tests/golden/make_cli_golden.py -> cli_search.json / cli_helpers.json; the module
+imports here with numpy + pandas, its three loader hooks stubbed): this file
+reproduces every committed result exactly (tests/test_cli_golden.py).  The BM25
+arithmetic inside those runs is oracle/bm25.py (rank_bm25 is absent: unpinned).
+The **app flavour stays unpinned** beyond the pinned primitives and the statements it
+shares with the cli flavour: app/app_product_search.py does ``import streamlit`` at
+module level (not installed), and the reference's tests pin no fused value.
 """
 from __future__ import annotations
 

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 import threading
 
-from .build import DEBUG_LIB_PATH, LIB_PATH
+from .build import DEBUG_BUILD_ID, BUILD_ID, DEBUG_LIB_PATH, LIB_PATH, library_digest
 
 c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 P = C.POINTER
@@ -111,6 +111,7 @@ def load():
             raise HipLibraryError(
                 f"{path} is missing: build it with `python __graft_entry__.py` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        _refuse_stale(path, DEBUG_BUILD_ID if debug else BUILD_ID, debug)
         # torch ships its own HIP runtime (libamdhip64, SONAME .7).  Importing it first makes
         # the dynamic linker bind librr_hip.so to that same runtime; loaded the other way
         # round the process would hold two runtimes and the second one sees no device.
@@ -118,11 +119,26 @@ def load():
         lib = C.CDLL(str(path))
         protos = dict(PROTOTYPES, **DEBUG_PROTOTYPES) if debug else PROTOTYPES
         for name, (res, args) in protos.items():
-            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                raise HipLibraryError(f"stale library: {path.name} lacks the declared symbol {name}; rebuild it with "
+                                      "`python __graft_entry__.py`") from None
             fn.restype = res
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def _refuse_stale(path, build_id, debug: bool) -> None:
+    """A library built from other sources than the ones beside it (csrc/, include/rr_hip.h, the flags) must not be
+    bound against today's prototypes: its buildid file holds the digest of what it was built from."""
+    have = build_id.read_text().strip() if build_id.exists() else None
+    if have != library_digest(debug):
+        raise HipLibraryError(
+            f"stale library: {path.name} was built from other sources than the ones in csrc/ "
+            f"(buildid {'missing' if have is None else have[:12]} != {library_digest(debug)[:12]}); "
+            "rebuild it with `python __graft_entry__.py`")
 
 
 def check(rc: int, what: str = "") -> None:

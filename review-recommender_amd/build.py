@@ -47,13 +47,19 @@ def _headers(debug: bool = False):
 FLTQ_ABLATIONS = "128,1,2,3,4,8,64,66,1025,1026,1027,1028,1029,1030"      # tools/fltq_ablate.py variants 3000 + n (rr_dense_flt.hip: RR_FLTQA_CASE)
 
 
-def check_generated(debug: bool = False) -> None:
-    """csrc/rr_fltq_loop.inc is generated (gen_fltq_loop.py) and committed: a stale copy must not build.  The debug
+def check_generated(debug: bool = False, regenerate: bool = False) -> None:
+    """csrc/rr_fltq_loop.inc is generated (gen_fltq_loop.py) and COMMITTED: a copy that differs from what the generator
+    prints must not build -- this raises instead of rewriting the shipped hand-scheduled loop behind the reader's back
+    (`python -m review_recommender_amd.build --regenerate`, or RR_REGENERATE=1, writes the file on purpose).  The debug
     harness's timing ablations of that loop (rr_fltq_loop_abl.inc) are generated on demand and not committed."""
     gen = subprocess.run([os.sys.executable, str(CSRC / "gen_fltq_loop.py")], capture_output=True, text=True, check=True)
     inc = CSRC / "rr_fltq_loop.inc"
     if not inc.exists() or inc.read_text() != gen.stdout:
-        inc.write_text(gen.stdout)
+        if regenerate or os.environ.get("RR_REGENERATE") == "1":
+            inc.write_text(gen.stdout)
+        else:
+            raise RuntimeError(f"{inc} differs from the output of gen_fltq_loop.py: regenerate it on purpose with "
+                               "`python -m review_recommender_amd.build --regenerate` and commit the result")
     if debug:
         gen = subprocess.run([os.sys.executable, str(CSRC / "gen_fltq_loop.py"), "--abl", FLTQ_ABLATIONS],
                              capture_output=True, text=True, check=True)
@@ -132,4 +138,6 @@ def build_library(force: bool = False, verbose: bool = False, jobs: int = 0, deb
 
 if __name__ == "__main__":
     import sys
+    if "--regenerate" in sys.argv:
+        check_generated(regenerate=True)
     print(build_library(force="--force" in sys.argv, verbose=True, debug="--debug" in sys.argv))

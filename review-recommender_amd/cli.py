@@ -6,10 +6,12 @@ CLI flavour of the pipeline (pool floor 100, no trust factor, BM25 aligned by sk
     python -m review_recommender_amd.cli -q "wireless headphones" -k 10 --data-dir data/processed \
         [--qvec-npy query.npy] [--json-out out.json]
 
-The query encoder (sentence-transformers BAAI/bge-small-en-v1.5) and the cross-encoder are
-loaded when the package is installed and the weights are on disk; offline, pass the query
-embedding with --qvec-npy and reranking degrades to zeros like the reference does when the
-model cannot be loaded (app/test.py:217-222).
+The query encoder and the cross-encoder run on the GPU (csrc/rr_ce.hip) from local Hugging Face
+model directories (--emb-model-dir / --rerank-model-dir); without an encoder pass the query
+embedding with --qvec-npy.  Reranking degrades to zeros like the reference does when the model
+cannot be loaded (app/test.py:217-222).  Loading the two models by hub NAME through
+sentence-transformers (a torch backend, what app/test.py:91-98 does) is not part of the product
+path: it happens only with the explicit --allow-hub switch.
 """
 from __future__ import annotations
 
@@ -49,13 +51,16 @@ def parse_args(argv=None):
                          "runs on the GPU (csrc/rr_ce.hip); nothing is fetched")
     ap.add_argument("--rerank-model-dir", type=str, default=os.environ.get("RERANK_MODEL_DIR", ""),
                     help="local Hugging Face directory of the cross-encoder reranker, likewise")
+    ap.add_argument("--allow-hub", action="store_true",
+                    help="opt in to sentence-transformers by model name (EMB_MODEL / RERANK_MODEL, app/test.py:28-29) for "
+                         "whatever model no local directory was given; off by default: the product path is the GPU one")
     return ap.parse_args(argv)
 
 
 def _load_encoders(args=None):
-    """Query encoder and reranker: local model directories on the GPU when given (--emb-model-dir / --rerank-model-dir),
-    else sentence-transformers by model name as the reference does (app/test.py:91-104) when that package and its
-    weights are present.  A reranker that cannot be loaded degrades to zeros with the reference's warning."""
+    """Query encoder and reranker from local model directories, on the GPU (--emb-model-dir / --rerank-model-dir).
+    Only with --allow-hub: sentence-transformers by model name as the reference does (app/test.py:91-104) for a model
+    no directory was given for.  A reranker that cannot be loaded degrades to zeros with the reference's warning."""
     enc = ce = None
     if args is not None and (args.emb_model_dir or args.rerank_model_dir):
         from .cross_encoder import CrossEncoder, QueryEncoder
@@ -66,11 +71,11 @@ def _load_encoders(args=None):
                 ce = CrossEncoder.from_pretrained_dir(args.rerank_model_dir, device=args.device)
             except Exception as e:   # app/test.py:220-222
                 print(f"[warn] cross-encoder load failed: {e}; skipping reranker.", flush=True)
-        if enc is not None:
-            return enc, ce
+    if args is None or not args.allow_hub:
+        return enc, ce
     try:
         from sentence_transformers import CrossEncoder, SentenceTransformer
-        enc = SentenceTransformer(EMB_MODEL)
+        enc = enc or SentenceTransformer(EMB_MODEL)
         try:
             ce = ce or CrossEncoder(RERANK_MODEL)
         except Exception as e:   # app/test.py:220-222
@@ -87,8 +92,8 @@ def main(argv=None) -> int:
     qvec = np.load(args.qvec_npy).astype(np.float32).reshape(-1) if args.qvec_npy else None
     enc, ce = _load_encoders(args) if (qvec is None or args.rerank_model_dir) else (None, None)
     if qvec is None and enc is None:
-        raise SystemExit(f"[ERR] loading/encoding with {EMB_MODEL} failed: sentence-transformers or its weights "
-                         "are unavailable; pass --qvec-npy")          # app/test.py:234-235
+        raise SystemExit(f"[ERR] loading/encoding with {EMB_MODEL} failed: no query encoder; pass --emb-model-dir or "
+                         "--qvec-npy (or opt in to the hub loader with --allow-hub)")          # app/test.py:234-235
     try:
         engine = SearchEngine.from_artifacts(args.data_dir, encoder=enc, cross_encoder=ce, flavour="cli",
                                              device=args.device)

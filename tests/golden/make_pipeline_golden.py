@@ -3,10 +3,12 @@
 
     python tests/golden/make_pipeline_golden.py
 
-** oracle-generated, reference-unpinned **: the reference's run_search / CLI search cannot be imported here
-(streamlit absent, hub fetches) and its tests pin no fused value; these files freeze what the build's statement-by-
-statement restatement produces, so that the oracle cannot drift silently together with the product (both are
-builder code).  The dense / primitive pieces underneath ARE pinned by the reference's utils.py (make_golden.py).
+** oracle-generated **: these files freeze what the build's statement-by-statement restatement produces, so that the
+oracle cannot drift silently together with the product (both are builder code).  The app flavour's run_search cannot
+be imported here (`import streamlit` at module level, app/app_product_search.py:9) and the reference's tests pin no
+fused value; the CLI flavour of the same oracle IS pinned by a run of the reference's own app/test.py -- see
+make_cli_golden.py / cli_search.json, which are the reference-run fixtures -- and the dense / primitive pieces
+underneath by the reference's utils.py (make_golden.py).
 
   pipeline_10k.npz   N = 10 000 x 384 (BASELINE config 1 shape, seeds below): for every case the parameter tuple,
                      the query, the pool rows in pool order, the eight pool columns, the top-k rows and finals.
