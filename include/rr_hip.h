@@ -324,6 +324,43 @@ int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n_queries, i
 int rr_dense_select_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t top_k,
                         const float* d_floor, int64_t* d_out_rows, float* d_out_scores, void* stream);
 
+/* PIPELINED K1 ("keep K1 -> K2-gather -> allgather -> K3 on-stream ... pipeline batches"): the same two
+ * phases with an explicit SCAN SLOT (0, 1 or 2).  A slot holds what one batch's scan writes and its selection reads (staged
+ * queries, their bf16 planes and error bounds, tile / group maxima, the parked phase-1 state); the index has three, so batch
+ * i + 1 can be scanned into one slot on one stream while batch i's selection (then K2, K3 and the answer's copy) reads the
+ * other on ANOTHER stream.  The library orders scan and selection of a slot with events (a scan waits for the slot's
+ * previous selection, a selection for its scan and for the previous selection's use of the shared rescoring scratch);
+ * calls on one handle stay serialised on the host.  kth = 0 with d_bound = NULL: no bound is computed (single GPU);
+ * d_floor may be NULL (the shard selects on its own threshold).  rr_dense_scan_dev / rr_dense_select_dev above are
+ * slot 0; every other search entry point uses slot 0 and voids a scan parked there.
+ * The scan kernel keeps one 512-register wave on every SIMD of a CU it runs on, so a second stream only makes progress on
+ * CUs the scan does not hold: give the scans a stream masked to part of the device (rr_stream_create_cu_range), tell the
+ * index how many CUs that is (rr_index_set_scan_cus: every scan's resident grid is sized for it), and run the selections
+ * on a stream masked to the rest.  (Replaces nothing in the reference: utils.py:111-124 is one blocking call.) */
+int rr_dense_scan_slot_dev(rr_index* ix, int32_t slot, const float* d_queries, int32_t n_queries, int32_t top_k, int32_t kth,
+                           float* d_bound, int32_t* applied, void* stream);
+int rr_dense_select_slot_dev(rr_index* ix, int32_t slot, int32_t n_queries, int32_t top_k, const float* d_floor,
+                             int64_t* d_out_rows, float* d_out_scores, void* stream);
+/* The selection in its three steps, each possibly on a stream of its own (`parts` = any combination, launched in this order):
+ *   RR_SELECT_LIST     per query the 8-row M-tiles whose scan bound reaches the threshold (one workgroup per query: latency-
+ *                      bound, a few CUs do);
+ *   RR_SELECT_RESCORE  the exact per-row scores of the listed M-tiles: a gather of ~3 MB of rows per query (HBM-bound: wants
+ *                      the bandwidth of the many CUs -- e.g. the scans' stream, behind the next batch's scan);
+ *   RR_SELECT_ORDER    the top_k of the rescored rows into d_out_rows / d_out_scores + the exact fallbacks of flagged queries.
+ * Pass the same d_floor (or NULL) to every part of a batch (LIST reads it; the other two only act on whether there is one);
+ * the outputs may be NULL unless ORDER is among the parts.  rr_dense_select_slot_dev = all three. */
+#define RR_SELECT_LIST    1
+#define RR_SELECT_RESCORE 2
+#define RR_SELECT_ORDER   4
+int rr_dense_select_part_dev(rr_index* ix, int32_t slot, int32_t parts, int32_t n_queries, int32_t top_k, const float* d_floor,
+                             int64_t* d_out_rows, float* d_out_scores, void* stream);
+/* A hipStream_t (as void*) whose kernels run only on CUs [first_cu, first_cu + n_cus) of `device`, counted in the driver's
+ * CU-mask order (bit i sits on XCD i % 8: a contiguous range takes the same share of every XCD).  Destroy with rr_stream_destroy. */
+int rr_stream_create_cu_range(int32_t device, int32_t first_cu, int32_t n_cus, void** out_stream);
+int rr_stream_destroy(void* stream);
+/* How many CUs the stream of this index's scans may use (0 or the device's CU count = all). */
+int rr_index_set_scan_cus(rr_index* ix, int32_t n_cus);
+
 /* Stream helpers for callers that chain *_dev calls. */
 int rr_index_stream(rr_index* ix, void** out_stream);
 int rr_index_synchronize(rr_index* ix);

@@ -58,6 +58,12 @@ PROTOTYPES = {
     "rr_index_set_scan_mode": (C.c_int, [c_vp, c_i32]),
     "rr_dense_scan_dev": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, P(c_i32), c_vp]),
     "rr_dense_select_dev": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rr_dense_scan_slot_dev": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, P(c_i32), c_vp]),
+    "rr_dense_select_slot_dev": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rr_dense_select_part_dev": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rr_stream_create_cu_range": (C.c_int, [c_i32, c_i32, c_i32, P(c_vp)]),
+    "rr_stream_destroy": (C.c_int, [c_vp]),
+    "rr_index_set_scan_cus": (C.c_int, [c_vp, c_i32]),
     "rr_bm25_create": (C.c_int, [c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_vp, c_vp, c_vp, c_f64, c_f64, c_f64, c_i64, P(c_vp)]),
     "rr_bm25_create_dev": (C.c_int, [c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,

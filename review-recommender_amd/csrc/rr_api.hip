@@ -150,6 +150,9 @@ extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim
     if (e == hipSuccess) e = hipEventCreate(&ix->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ix->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_done, hipEventDisableTiming);
+    for (int i = 0; i < RR_SCAN_SLOTS && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->slot_ev[i], hipEventDisableTiming);
+    if (e == hipSuccess && (hipDeviceGetAttribute(&ix->n_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cus < 1))
+        ix->n_cus = 256;
     for (int i = 0; i < rr_index::kRing && e == hipSuccess; ++i) {
         e = hipEventCreate(&ix->ring0[i]);
         if (e == hipSuccess) e = hipEventCreate(&ix->ring1[i]);
@@ -158,6 +161,7 @@ extern "C" int rr_index_create(const void* h_matrix, int64_t n_rows, int32_t dim
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_flag_list, sizeof(int32_t) * 16);
     if (e == hipSuccess) e = hipMalloc(&ix->d_qplanes, (size_t)2 * 3 * 64 * 384 * 2)   /* two sets of query planes (paired filter-scan launches) */;
     if (e == hipSuccess) e = hipMalloc(&ix->d_x3, rr_x3_scratch_bytes());
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->d_eps, sizeof(float) * RR_SEL_MAXQ);
     if (e == hipSuccess) e = hipMalloc(&ix->d_q, sizeof(float) * (size_t)RR_MAX_BATCH * ix->dim_pad);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_rows_out, sizeof(int64_t) * (size_t)RR_MAX_BATCH * RR_MAX_POOL);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->d_scores_out, sizeof(float) * (size_t)RR_MAX_BATCH * RR_MAX_POOL);
@@ -278,8 +282,14 @@ extern "C" int rr_index_destroy(rr_index* ix) {
     if (ix->stream) hipStreamSynchronize(ix->stream);
     if (ix->d_matrix && ix->owns_matrix) hipFree(ix->d_matrix);
     hipFree(ix->d_n_reviews); hipFree(ix->d_avg_stars); hipFree(ix->d_log1p_n);
-    hipFree(ix->d_sims); hipFree(ix->d_gmax); hipFree(ix->d_smax); hipFree(ix->d_sel_trace); hipFree(ix->d_flag_list); hipFree(ix->d_qplanes); hipFree(ix->d_x3); hipFree(ix->d_q);
-    hipFree(ix->d_rows_out); hipFree(ix->d_scores_out); hipFree(ix->d_shadow); hipFree(ix->d_flt_samp); hipFree(ix->d_flt_sigma); hipFree(ix->d_flt_prog); free(ix->flt_pending);
+    rr_slot_park(ix);          // both slots' buffers now sit in ix->parked[]
+    for (rr_scan_slot& s : ix->parked) {
+        hipFree(s.d_q); hipFree(s.d_qplanes); hipFree(s.d_eps); hipFree(s.d_gmax); hipFree(s.d_smax);
+        hipFree(s.d_flt_samp); hipFree(s.d_flt_sigma); hipFree(s.d_flt_prog); free(s.flt_pending);
+    }
+    hipFree(ix->d_sims); hipFree(ix->d_sel_trace); hipFree(ix->d_flag_list); hipFree(ix->d_x3);
+    hipFree(ix->d_rows_out); hipFree(ix->d_scores_out); hipFree(ix->d_shadow);
+    for (int i = 0; i < RR_SCAN_SLOTS; ++i) if (ix->slot_ev[i]) hipEventDestroy(ix->slot_ev[i]);
     if (ix->ev0) hipEventDestroy(ix->ev0);
     if (ix->ev1) hipEventDestroy(ix->ev1);
     if (ix->ev_done) hipEventDestroy(ix->ev_done);
@@ -289,6 +299,45 @@ extern "C" int rr_index_destroy(rr_index* ix) {
     }
     if (ix->stream) hipStreamDestroy(ix->stream);
     delete ix;
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------- CU-masked streams (pipelined K1)
+// A stream whose kernels may only run on CUs [first_cu, first_cu + n_cus) of the device, in the driver's mask order (bit i =
+// XCD i % 8, so a contiguous range takes the same share of every XCD and of its L2).  What lets batch i's selection /
+// K2 / K3 run on a few CUs of their own while batch i + 1's scan -- one 512-register wave per SIMD: nothing else fits on a
+// CU it occupies -- holds the rest.
+extern "C" int rr_stream_create_cu_range(int32_t device, int32_t first_cu, int32_t n_cus, void** out_stream) {
+    RR_REQUIRE(out_stream, "rr_stream_create_cu_range: NULL out");
+    *out_stream = nullptr;
+    int ndev = 0, cus = 0;
+    RR_HIP_TRY(hipGetDeviceCount(&ndev));
+    RR_REQUIRE(device >= 0 && device < ndev, "rr_stream_create_cu_range: device %d not in [0,%d)", device, ndev);
+    RR_HIP_TRY(hipSetDevice(device));
+    RR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    RR_REQUIRE(first_cu >= 0 && n_cus >= 1 && first_cu + n_cus <= cus, "rr_stream_create_cu_range: CUs [%d, %d) outside [0, %d)",
+               first_cu, first_cu + n_cus, cus);
+    uint32_t mask[32] = {0};
+    RR_REQUIRE(cus <= 32 * 32, "rr_stream_create_cu_range: %d CUs", cus);
+    for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c / 32] |= 1u << (c % 32);
+    hipStream_t st = nullptr;
+    RR_HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask));
+    *out_stream = (void*)st;
+    return RR_OK;
+}
+
+extern "C" int rr_stream_destroy(void* stream) {
+    if (!stream) return RR_OK;
+    RR_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    RR_HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return RR_OK;
+}
+
+extern "C" int rr_index_set_scan_cus(rr_index* ix, int32_t n_cus) {
+    RR_REQUIRE(ix, "rr_index_set_scan_cus: NULL handle");
+    RR_REQUIRE(n_cus >= 0 && n_cus <= ix->n_cus, "rr_index_set_scan_cus: %d outside [0, %d]", n_cus, ix->n_cus);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    ix->scan_cus = n_cus == ix->n_cus ? 0 : n_cus;
     return RR_OK;
 }
 

@@ -61,31 +61,86 @@ __device__ __forceinline__ int64_t rr_lower_bound(const int32_t* __restrict__ a,
     return lo;
 }
 
+// first index in [lo, hi) with a[i] >= key, found by a whole wave: 64 probes per step (log64 steps instead of log2: a
+// workgroup's first use of a long postings list is a chain of DEPENDENT loads -- 4 instead of 23 at df = 10M)
+__device__ __forceinline__ int64_t rr_lower_bound_wave(const int32_t* __restrict__ a, int64_t lo, int64_t hi, int32_t key) {
+    const int lane = threadIdx.x & 63;
+    while (hi - lo > 64) {
+        const int64_t stride = (hi - lo + 63) >> 6;
+        const int64_t at = lo + lane * stride;
+        const bool below = at < hi && a[at] < key;          // (sorted: the lanes that answer "below" are a prefix)
+        const int c = __popcll(__ballot(below));
+        if (c == 0) return lo;                               // a[lo] >= key
+        const int64_t nlo = lo + (int64_t)(c - 1) * stride + 1, nhi = lo + (int64_t)c * stride;
+        lo = nlo;
+        hi = nhi < hi ? nhi : hi;
+    }
+    const bool below = lo + lane < hi && a[lo + lane] < key;
+    return lo + __popcll(__ballot(below));
+}
+
+#define RR_SLICE_TERMS 16     // query tokens whose posting blocks a workgroup locates in one go
+// get_scores: see the file header.  `dirty[slice]` (in/out): whether the slice of `out` holds anything but zeros -- `out`
+// is all zeros when the handle is created, a call writes a slice only if one of its tokens has a posting in it or the
+// previous call left something there (rare-term queries touch a few slices of the 80 MB at 10M documents, not all).
 __global__ __launch_bounds__(256) void rr_bm25_slices(rr_bm25_view v, const int32_t* __restrict__ terms,
-                                                      int n_terms_q, double* __restrict__ out) {
+                                                      int n_terms_q, double* __restrict__ out, unsigned char* __restrict__ dirty) {
     __shared__ double acc[RR_SLICE];
-    __shared__ int64_t range[2];
-    const int tid = threadIdx.x;
+    __shared__ int64_t range[RR_SLICE_TERMS][2];
+    __shared__ int touched;
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int64_t d0 = (int64_t)blockIdx.x * RR_SLICE;
     const int64_t d1 = d0 + RR_SLICE < v.n_docs ? d0 + RR_SLICE : v.n_docs;
     for (int i = tid; i < RR_SLICE; i += 256) acc[i] = 0.0;
-    __syncthreads();
-    for (int j = 0; j < n_terms_q; ++j) {
-        const int32_t t = terms[j];
-        if (t < 0 || t >= v.n_terms) continue;  // idf.get(t) -> 0: contributes +0.0
-        const int64_t s = v.post_indptr[t], e = v.post_indptr[t + 1];
-        if (tid < 2)
-            range[tid] = rr_lower_bound(v.post_docs, s, e, (int32_t)(tid == 0 ? d0 : d1));
-        __syncthreads();
-        const int64_t lo = range[0], hi = range[1];
-        const double idf = v.idf[t];
-        for (int64_t p = lo + tid; p < hi; p += 256) {
-            const int32_t d = v.post_docs[p];
-            acc[d - d0] += rr_bm25_term(idf, v.post_tf[p], v.doc_len[d], v.avgdl, v.k1, v.b);
+    if (tid == 0) touched = 0;
+    for (int j0 = 0; j0 < n_terms_q; j0 += RR_SLICE_TERMS) {
+        const int nj = n_terms_q - j0 < RR_SLICE_TERMS ? n_terms_q - j0 : RR_SLICE_TERMS;
+        __syncthreads();                                     // (the previous chunk's ranges have been used)
+        // the block of every token's postings that falls into [d0, d1): 2 nj searches, one per wave at a time
+        for (int sidx = wave; sidx < 2 * nj; sidx += 4) {
+            const int32_t t = terms[j0 + (sidx >> 1)];
+            int64_t r = 0;
+            if (t >= 0 && t < v.n_terms)                     // (idf.get(t) -> 0 otherwise: an empty block, contributes +0.0)
+                r = rr_lower_bound_wave(v.post_docs, v.post_indptr[t], v.post_indptr[t + 1], (int32_t)((sidx & 1) ? d1 : d0));
+            if ((tid & 63) == 0) range[sidx >> 1][sidx & 1] = r;
         }
         __syncthreads();
+        // tokens in query order (a document's additions are the reference's); the first 256 postings of the NEXT token's
+        // block are fetched while this one's are added
+        int32_t nd = 0, ntf = 0, ndl = 0;
+        bool nhave = false;
+        {
+            const int64_t p = range[0][0] + tid;
+            nhave = p < range[0][1];
+            if (nhave) { nd = v.post_docs[p]; ntf = v.post_tf[p]; ndl = v.doc_len[nd]; }
+        }
+        for (int j = 0; j < nj; ++j) {
+            const int64_t lo = range[j][0], hi = range[j][1];
+            const int32_t t = terms[j0 + j];
+            const bool have = nhave;
+            const int32_t d = nd, tf = ntf, dl = ndl;
+            if (j + 1 < nj) {
+                const int64_t p = range[j + 1][0] + tid;
+                nhave = p < range[j + 1][1];
+                if (nhave) { nd = v.post_docs[p]; ntf = v.post_tf[p]; ndl = v.doc_len[nd]; }
+            }
+            if (hi > lo) {
+                const double idf = v.idf[t];
+                if (tid == 0) touched = 1;
+                if (have) acc[d - d0] += rr_bm25_term(idf, tf, dl, v.avgdl, v.k1, v.b);
+                for (int64_t p = lo + 256 + tid; p < hi; p += 256) {
+                    const int32_t dd = v.post_docs[p];
+                    acc[dd - d0] += rr_bm25_term(idf, v.post_tf[p], v.doc_len[dd], v.avgdl, v.k1, v.b);
+                }
+            }
+            __syncthreads();                                 // a document takes one addition per token: tokens in order
+        }
     }
-    for (int64_t i = tid; i < d1 - d0; i += 256) out[d0 + i] = acc[i];
+    __syncthreads();
+    const bool write = touched || dirty[blockIdx.x];
+    if (write)
+        for (int64_t i = tid; i < d1 - d0; i += 256) out[d0 + i] = acc[i];
+    if (tid == 0) dirty[blockIdx.x] = (unsigned char)touched;
 }
 
 template <int MODE>
@@ -242,6 +297,7 @@ extern "C" int rr_bm25_destroy(rr_bm25* bm) {
         hipFree(bm->d_doc_len); hipFree(bm->d_idf);
     }
     hipFree(bm->d_scores);
+    hipFree(bm->d_dirty);
     if (bm->stream) hipStreamDestroy(bm->stream);
     delete bm;
     return RR_OK;
@@ -255,15 +311,21 @@ extern "C" int rr_bm25_get_scores(rr_bm25* bm, const int32_t* h_term_ids, int32_
                "rr_bm25_get_scores: %d query tokens out of [0,4096]", n_terms_in_query);
     std::lock_guard<std::mutex> lk(bm->mu);
     RR_HIP_TRY(hipSetDevice(bm->device));
-    if (!bm->d_scores) RR_HIP_TRY(hipMalloc((void**)&bm->d_scores, sizeof(double) * (size_t)bm->n_docs));
+    const unsigned grid = (unsigned)((bm->n_docs + RR_SLICE - 1) / RR_SLICE);
+    if (!bm->d_scores) {
+        // all zeros once; from then on a call writes only the slices it (or its predecessor) put something in
+        RR_HIP_TRY(hipMalloc((void**)&bm->d_scores, sizeof(double) * (size_t)bm->n_docs));
+        RR_HIP_TRY(hipMalloc((void**)&bm->d_dirty, grid));
+        RR_HIP_TRY(hipMemsetAsync(bm->d_scores, 0, sizeof(double) * (size_t)bm->n_docs, bm->stream));
+        RR_HIP_TRY(hipMemsetAsync(bm->d_dirty, 0, grid, bm->stream));
+    }
     int32_t* d_terms = nullptr;
     RR_HIP_TRY(hipMalloc((void**)&d_terms, sizeof(int32_t) * (size_t)(n_terms_in_query + 1)));
     if (n_terms_in_query)
         hipMemcpyAsync(d_terms, h_term_ids, sizeof(int32_t) * n_terms_in_query, hipMemcpyHostToDevice,
                        bm->stream);
-    const unsigned grid = (unsigned)((bm->n_docs + RR_SLICE - 1) / RR_SLICE);
     hipLaunchKernelGGL(rr_bm25_slices, dim3(grid), dim3(256), 0, bm->stream, rr_view(bm), d_terms,
-                       n_terms_in_query, bm->d_scores);
+                       n_terms_in_query, bm->d_scores, bm->d_dirty);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipMemcpyAsync(h_out_scores, bm->d_scores, sizeof(double) * (size_t)bm->n_docs,

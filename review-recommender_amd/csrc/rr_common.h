@@ -32,6 +32,28 @@ void rr_set_error(const char* fmt, ...);
     } while (0)
 
 // ---------------------------------------------------------------- handles
+// What ONE batch's scan writes and its selection reads (the staged queries, their bf16 planes and error bounds, the tile /
+// group maxima, the prefilter's thresholds, the parked phase-1 state).  An index has RR_SCAN_SLOTS of them
+// ("slots"): the pipelined K1 (rr_dense_scan_slot_dev / rr_dense_select_part_dev) scans batch i + 1 into one slot on one
+// stream while batch i's selection reads another on another stream (three: a batch's last selection part, its fallbacks
+// included, may still hold its slot when the scan after next starts).  The ACTIVE slot's pointers live in the rr_index
+// fields of the same names (every launch site reads them there); rr_slot_activate swaps them under the handle's mutex.
+#define RR_SCAN_SLOTS 3
+struct rr_scan_slot {
+    float* d_q = nullptr;
+    void* d_qplanes = nullptr;
+    float* d_eps = nullptr;
+    float* d_gmax = nullptr;
+    uint32_t* d_smax = nullptr;
+    int32_t maxima_q = 0;
+    float* d_flt_samp = nullptr;
+    float* d_flt_sigma = nullptr;
+    uint32_t* d_flt_prog = nullptr;
+    uint32_t flt_seq = 0;
+    bool flt_prep_fresh = false;
+    void* flt_pending = nullptr;
+};
+
 struct rr_index {
     int device = 0;
     int64_t n_rows = 0;
@@ -51,7 +73,9 @@ struct rr_index {
     int32_t* d_sel_trace = nullptr;  // [8][4] path trace of the last selection launch
     int32_t* d_flag_list = nullptr;  // [16] count + the (at most 8) flagged queries of a filter call served by the single-query chain
     uint32_t* d_smax = nullptr;  // [qcap][n_super] ordered keys of super-tile maxima
-    int32_t scratch_q = 0;
+    int32_t scratch_q = 0;       // query slots d_sims was sized for
+    int32_t maxima_q = 0;        // ... and d_gmax / d_smax (per slot)
+    float* d_eps = nullptr;      // [RR_SEL_MAXQ] error bounds of the filter scan's scores (rr_x3_scratch.eps; per slot)
     float* d_q = nullptr;        // staged queries [RR_MAX_BATCH][dim_pad]
     float norm_bound = -1.f;     // upper bound of the largest row norm; < 0: not computed (any write to the matrix resets it)
     float delta_bound = 0.f;     // ... and of the largest ||row - bf16(row)||
@@ -81,6 +105,16 @@ struct rr_index {
     hipEvent_t ev_done = nullptr;
     hipStream_t last_stream = nullptr;
     bool has_done = false;
+    // pipelined K1: the inactive slot's state (rr_scan_slot) and which slot the fields above hold
+    rr_scan_slot parked[RR_SCAN_SLOTS];
+    int cur_slot = 0;
+    // the last launch sequence that touched a slot (its scan, or a part of its selection), and the stream it went to: the
+    // next one on ANOTHER stream waits for it.  (ev_done / last_stream above: the same for the selection scratch all slots share.)
+    hipEvent_t slot_ev[RR_SCAN_SLOTS] = {};
+    hipStream_t slot_stream[RR_SCAN_SLOTS] = {};
+    bool slot_has[RR_SCAN_SLOTS] = {};
+    int32_t n_cus = 0;           // CUs of the device
+    int32_t scan_cus = 0;        // rr_index_set_scan_cus: CUs the scans' stream may use (0 = all): sizes every scan's resident grid
     bool timing_valid = false;
     static const int kRing = 512;               // event pairs around every scan launch
     hipEvent_t ring0[kRing] = {}, ring1[kRing] = {};
@@ -102,7 +136,8 @@ struct rr_bm25 {
     double* d_idf = nullptr;
     double avgdl = 1.0, k1 = 1.5, b = 0.75;
     bool owns_arrays = true;
-    double* d_scores = nullptr;   // n_docs, scratch of get_scores
+    double* d_scores = nullptr;   // n_docs, scratch of get_scores (all zeros outside the slices d_dirty marks)
+    unsigned char* d_dirty = nullptr;   // per RR_SLICE documents: the last get_scores left something there
     hipStream_t stream = nullptr;
     std::mutex mu;
 };

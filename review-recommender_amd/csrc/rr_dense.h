@@ -43,6 +43,9 @@ static inline void rr_matrix_written(rr_index* ix) {
     ix->norm_bound = -1.f;
     ix->shadow_valid = false;
 }
+// scan slots (rr_common.h: rr_scan_slot): which of the two sets of per-batch scan state the index fields describe
+int rr_slot_activate(rr_index* ix, int slot);
+void rr_slot_park(rr_index* ix);
 // HIP-event pair around a scan launch (rr_index_scan_stats).
 int rr_scan_events_begin(rr_index* ix, hipStream_t st);
 void rr_scan_events_end(rr_index* ix, int slot, hipStream_t st);
@@ -95,9 +98,11 @@ int rr_dense_chunk_x3(rr_index* ix, const float* d_q, int nq, int pool, int64_t*
 // the matrix has no finite row-norm bound
 // `phase`: 0 = scan + selection; 1 = scan only, bound[q] (rr_group_kth with `kth`) written, state kept in the index;
 // 2 = selection of the scan phase 1 left behind, with `floor` (row shards)
+// `parts` (phase 2 only): which of the selection's three steps to launch -- 1 the M-tile lists, 2 the rescoring, 4 the
+// ordering + the flagged queries' fallbacks (the parked scan stays valid until the last one has been launched)
 int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
                        float* d_scores, hipStream_t st, int phase = 0, int kth = 0, float* d_bound = nullptr,
-                       const float* d_floor = nullptr);
+                       const float* d_floor = nullptr, int parts = 7);
 // any other search on the index makes a parked phase-1 scan void
 void rr_flt_drop_pending(rr_index* ix);
 // fp32 rows (device, n x dim) -> the index's bf16 matrix rows [first, first + n), optional l2 normalise

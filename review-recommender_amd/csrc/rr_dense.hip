@@ -1080,7 +1080,8 @@ rr_x3_scratch rr_x3_scratch_of(const rr_index* ix) {
     s.count = reinterpret_cast<int32_t*>(p);    p += sizeof(int32_t) * RR_SEL_MAXQ;
     s.tau = reinterpret_cast<uint32_t*>(p);     p += sizeof(uint32_t) * RR_SEL_MAXQ;
     s.fb = reinterpret_cast<int32_t*>(p);       p += sizeof(int32_t) * RR_SEL_MAXQ;
-    s.eps = reinterpret_cast<float*>(p);        p += sizeof(float) * RR_SEL_MAXQ;
+    p += sizeof(float) * RR_SEL_MAXQ;            // (eps used to live here: it is per scan slot now, ix->d_eps)
+    s.eps = ix->d_eps;
     s.sc = reinterpret_cast<float*>(p);
     return s;
 }
@@ -1166,17 +1167,39 @@ __global__ void rr_l2norm_f32(float* __restrict__ mat, int64_t n_rows, int dim_p
 }
 
 // ------------------------------------------------------------------ host side
+// Tile / group maxima of the ACTIVE scan slot, for launches of up to `nq` queries.
+static int rr_ensure_maxima(rr_index* ix, int nq) {
+    const size_t nm = nq >= RR_MFMA_MAXQ ? RR_FLT_MAXQ : nq;
+    if (ix->maxima_q >= (int)nm) return RR_OK;
+    const int64_t n_tiles = rr_round_up(ix->n_rows, 64) / 64;
+    if (ix->d_gmax) hipFree(ix->d_gmax);
+    if (ix->d_smax) hipFree(ix->d_smax);
+    ix->d_gmax = nullptr;
+    ix->d_smax = nullptr;
+    ix->maxima_q = 0;
+    const size_t groups_cap = (size_t)RR_MAX_SCAN_WAVES;   // one group maximum per scan wave
+    // tile / group maxima: up to RR_FLT_MAXQ queries per launch (x4: per-M-tile maxima of the matrix-core scans)
+    // (the filter scan uses 2 words per 64-row tile and query: two sets of them fit, + one line per scan wave behind them)
+    const size_t gmax_words = nm * n_tiles * 4 + (size_t)RR_MAX_SCAN_WAVES * RR_FLT_MAXQ;
+    RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * gmax_words));
+    // rr_scan_flt's store prefilter leaves the words of skipped tiles as they were: start from "-inf, no gaps" so that
+    // a never-written word cannot open anything (stale words of earlier launches can only add rescoring work)
+    RR_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->d_gmax, 0x0000FF80, gmax_words, nullptr));
+    RR_HIP_TRY(hipStreamSynchronize(nullptr));
+    RR_HIP_TRY(hipMalloc(&ix->d_smax, sizeof(uint32_t) * 2 * nm * groups_cap));
+    ix->maxima_q = (int32_t)nm;
+    return RR_OK;
+}
+
+// Score scratch (shared by both slots: only selections and fallbacks touch it) + the active slot's maxima.
 static int rr_ensure_scratch(rr_index* ix, int nq) {
+    const int rc = rr_ensure_maxima(ix, nq);
+    if (rc) return rc;
     if (ix->scratch_q >= nq || (ix->scratch_small && ix->scratch_q >= RR_MFMA_MAXQ)) return RR_OK;
     const int64_t n_tiles = rr_round_up(ix->n_rows, 64) / 64;
     if (ix->d_sims) hipFree(ix->d_sims);
-    if (ix->d_gmax) hipFree(ix->d_gmax);
-    if (ix->d_smax) hipFree(ix->d_smax);
     ix->d_sims = nullptr;
-    ix->d_gmax = nullptr;
-    ix->d_smax = nullptr;
     ix->scratch_q = 0;
-    const size_t groups_cap = (size_t)RR_MAX_SCAN_WAVES;   // one group maximum per scan wave
     // (more than 64 score slots only serve the sliced fallback of a filter call: when there is no room for them -- a very
     //  large index -- 64 slots do, and the fallback goes block by block: rr_dense_x3w_fallback_all)
     static const bool force_small = getenv("RR_SCRATCH_SMALL") != nullptr;   // (tests: the block-by-block fallback on a small index)
@@ -1189,17 +1212,41 @@ static int rr_ensure_scratch(rr_index* ix, int nq) {
         RR_HIP_TRY(hipMalloc(&ix->d_sims, sizeof(float) * (size_t)nq * n_tiles * 64));
         ix->scratch_small = true;
     }
-    // tile / group maxima: up to RR_FLT_MAXQ queries per launch (x4: per-M-tile maxima of the matrix-core scans)
-    const size_t nm = nq >= RR_MFMA_MAXQ ? RR_FLT_MAXQ : nq;
-    // (the filter scan uses 2 words per 64-row tile and query: two sets of them fit, + one line per scan wave behind them)
-    const size_t gmax_words = nm * n_tiles * 4 + (size_t)RR_MAX_SCAN_WAVES * RR_FLT_MAXQ;
-    RR_HIP_TRY(hipMalloc(&ix->d_gmax, sizeof(float) * gmax_words));
-    // rr_scan_flt's store prefilter leaves the words of skipped tiles as they were: start from "-inf, no gaps" so that
-    // a never-written word cannot open anything (stale words of earlier launches can only add rescoring work)
-    RR_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->d_gmax, 0x0000FF80, gmax_words, nullptr));
-    RR_HIP_TRY(hipStreamSynchronize(nullptr));
-    RR_HIP_TRY(hipMalloc(&ix->d_smax, sizeof(uint32_t) * 2 * nm * groups_cap));
     ix->scratch_q = nq;
+    return RR_OK;
+}
+
+// ---- scan slots (rr_common.h: rr_scan_slot)
+static void rr_slot_store(const rr_index* ix, rr_scan_slot& s) {
+    s.d_q = ix->d_q; s.d_qplanes = ix->d_qplanes; s.d_eps = ix->d_eps; s.d_gmax = ix->d_gmax; s.d_smax = ix->d_smax;
+    s.maxima_q = ix->maxima_q; s.d_flt_samp = ix->d_flt_samp; s.d_flt_sigma = ix->d_flt_sigma; s.d_flt_prog = ix->d_flt_prog;
+    s.flt_seq = ix->flt_seq; s.flt_prep_fresh = ix->flt_prep_fresh; s.flt_pending = ix->flt_pending;
+}
+static void rr_slot_fetch(rr_index* ix, const rr_scan_slot& s) {
+    ix->d_q = s.d_q; ix->d_qplanes = s.d_qplanes; ix->d_eps = s.d_eps; ix->d_gmax = s.d_gmax; ix->d_smax = s.d_smax;
+    ix->maxima_q = s.maxima_q; ix->d_flt_samp = s.d_flt_samp; ix->d_flt_sigma = s.d_flt_sigma; ix->d_flt_prog = s.d_flt_prog;
+    ix->flt_seq = s.flt_seq; ix->flt_prep_fresh = s.flt_prep_fresh; ix->flt_pending = s.flt_pending;
+}
+// (rr_index_destroy) every slot's buffers into ix->parked[], none left in the index fields
+void rr_slot_park(rr_index* ix) {
+    rr_slot_store(ix, ix->parked[ix->cur_slot]);
+    rr_slot_fetch(ix, rr_scan_slot());
+}
+// Makes `slot` the one the index fields describe (caller holds ix->mu).  Its small buffers are allocated at first use.
+int rr_slot_activate(rr_index* ix, int slot) {
+    RR_REQUIRE(slot >= 0 && slot < RR_SCAN_SLOTS, "scan slot %d outside [0, %d)", slot, RR_SCAN_SLOTS);
+    if (slot != ix->cur_slot) {
+        rr_slot_store(ix, ix->parked[ix->cur_slot]);
+        rr_slot_fetch(ix, ix->parked[slot]);
+        ix->parked[slot] = rr_scan_slot();
+        ix->cur_slot = slot;
+    }
+    if (!ix->d_q) {
+        RR_HIP_TRY(hipSetDevice(ix->device));
+        RR_HIP_TRY(hipMalloc(&ix->d_qplanes, (size_t)2 * 3 * 64 * 384 * 2));
+        RR_HIP_TRY(hipMalloc((void**)&ix->d_eps, sizeof(float) * RR_SEL_MAXQ));
+        RR_HIP_TRY(hipMalloc((void**)&ix->d_q, sizeof(float) * (size_t)RR_MAX_BATCH * ix->dim_pad));
+    }
     return RR_OK;
 }
 
@@ -1223,7 +1270,12 @@ rr_scan_geom rr_make_geom(const rr_index* ix, int resident_blocks) {
     G.n_rows = ix->n_rows;
     G.n_tiles = rr_round_up(ix->n_rows, 64) / 64;
     G.n_pad = G.n_tiles * 64;
-    const int64_t max_waves = (int64_t)resident_blocks * (RR_SCAN_THREADS / 64);
+    int64_t max_waves = (int64_t)resident_blocks * (RR_SCAN_THREADS / 64);
+    // (rr_index_set_scan_cus: the scans' stream is masked to scan_cus of the device's CUs -- a resident grid is that share)
+    if (ix->scan_cus > 0 && ix->n_cus > 0) {
+        max_waves = max_waves * ix->scan_cus / ix->n_cus;
+        if (max_waves < 1) max_waves = 1;
+    }
     G.tiles_per_wave = (G.n_tiles + max_waves - 1) / max_waves;
     G.n_waves = (int32_t)((G.n_tiles + G.tiles_per_wave - 1) / G.tiles_per_wave);
     G.qs = 0;
@@ -1364,15 +1416,28 @@ static int rr_dense_chunk_mfma(rr_index* ix, const float* d_q, int nq, int pool,
     return RR_OK;
 }
 
-// Orders this call's use of the handle's scratch behind the previous call's when the stream changed.
-static int rr_scratch_enter(rr_index* ix, hipStream_t st) {
-    if (ix->has_done && st != ix->last_stream) RR_HIP_TRY(hipStreamWaitEvent(st, ix->ev_done, 0));
+// Orders this call's use of the handle's scratch behind the previous call's when the stream changed.  Two resources:
+// the ACTIVE slot's scan state (written by its scan, read -- and, by the fallbacks, overwritten -- by the parts of its
+// selection) and the selection scratch all slots share (M-tile lists, rescored rows, stored scores): `select` says whether
+// the call touches the second.  Each records the last launch sequence that used it; a call on another stream waits for it.
+static int rr_scratch_enter(rr_index* ix, hipStream_t st, bool scan = true, bool select = true) {
+    (void)scan;
+    const int s = ix->cur_slot;
+    if (ix->slot_has[s] && ix->slot_stream[s] != st) RR_HIP_TRY(hipStreamWaitEvent(st, ix->slot_ev[s], 0));
+    if (select && ix->has_done && st != ix->last_stream) RR_HIP_TRY(hipStreamWaitEvent(st, ix->ev_done, 0));
     return RR_OK;
 }
-static int rr_scratch_leave(rr_index* ix, hipStream_t st) {
-    RR_HIP_TRY(hipEventRecord(ix->ev_done, st));
-    ix->last_stream = st;
-    ix->has_done = true;
+static int rr_scratch_leave(rr_index* ix, hipStream_t st, bool scan = true, bool select = true) {
+    (void)scan;
+    const int s = ix->cur_slot;
+    RR_HIP_TRY(hipEventRecord(ix->slot_ev[s], st));
+    ix->slot_stream[s] = st;
+    ix->slot_has[s] = true;
+    if (select) {
+        RR_HIP_TRY(hipEventRecord(ix->ev_done, st));
+        ix->last_stream = st;
+        ix->has_done = true;
+    }
     return RR_OK;
 }
 
@@ -1451,13 +1516,14 @@ __global__ void rr_pad_queries(const float* __restrict__ src, float* __restrict_
     dst[i] = (qi < nq && c < dim) ? src[(int64_t)qi * dim + c] : 0.f;
 }
 
-// Two-phase K1 for row shards (include/rr_hip.h): phase 1 = pad + prepare + scan + per-query bound.
-extern "C" int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t pool, int32_t kth,
-                                 float* d_bound, int32_t* applied, void* stream) {
-    RR_REQUIRE(ix && d_queries && d_bound && applied, "rr_dense_scan_dev: NULL argument");
+// Two-phase K1 (include/rr_hip.h): phase 1 = pad + prepare + scan [+ per-query bound, kth > 0] into scan slot `slot`.
+extern "C" int rr_dense_scan_slot_dev(rr_index* ix, int32_t slot, const float* d_queries, int32_t n_queries, int32_t pool,
+                                      int32_t kth, float* d_bound, int32_t* applied, void* stream) {
+    RR_REQUIRE(ix && d_queries && applied, "rr_dense_scan_dev: NULL argument");
     RR_REQUIRE(n_queries >= 1 && n_queries <= RR_MAX_BATCH, "rr_dense_scan_dev: n_queries %d out of [1,%d]", n_queries, RR_MAX_BATCH);
     RR_REQUIRE(pool >= 1 && pool <= RR_MAX_POOL && pool <= ix->n_rows, "rr_dense_scan_dev: pool %d out of range", pool);
-    RR_REQUIRE(kth >= 1 && kth <= pool, "rr_dense_scan_dev: kth %d out of [1, pool]", kth);
+    RR_REQUIRE(kth >= 0 && kth <= pool && (kth == 0) == (d_bound == nullptr),
+               "rr_dense_scan_dev: kth %d out of [1, pool] (or 0 with a NULL bound: no bound wanted)", kth);
     RR_REQUIRE(ix->d_matrix, "rr_dense_scan_dev: index has no matrix");
     *applied = 0;
     std::lock_guard<std::mutex> lk(ix->mu);
@@ -1474,7 +1540,9 @@ extern "C" int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n
     int rc = rr_device_visible(d_queries, &q_vis, "rr_dense_scan_dev (queries)");
     if (rc) return rc;
     d_queries = static_cast<const float*>(q_vis);
-    rc = rr_scratch_enter(ix, st);
+    rc = rr_slot_activate(ix, slot);
+    if (rc) return rc;
+    rc = rr_scratch_enter(ix, st, true, false);
     if (rc) return rc;
     rc = rr_ensure_scratch(ix, (int)rr_round_up(n_queries, RR_MFMA_MAXQ));
     if (rc) return rc;
@@ -1485,26 +1553,48 @@ extern "C" int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n
         hipLaunchKernelGGL(rr_pad_queries, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                            d_queries, ix->d_q, n_queries, ix->dim, ix->dim_pad, slots);
     rc = rr_dense_chunk_flt(ix, ix->d_q, n_queries, pool, nullptr, nullptr, st, 1, kth, d_bound, nullptr);
-    if (rc == RR_FLT_NO_BOUND || rc == RR_FLT_SMALL) return rr_scratch_leave(ix, st);     // not applied
+    if (rc == RR_FLT_NO_BOUND || rc == RR_FLT_SMALL) return rr_scratch_leave(ix, st, true, false);     // not applied
     if (rc) return rc;
     *applied = 1;
-    return rr_scratch_leave(ix, st);
+    return rr_scratch_leave(ix, st, true, false);
 }
 
-// phase 2 = selection / rescoring / ordering of the scan phase 1 left behind, M-tiles opened no further down than `d_floor`
-extern "C" int rr_dense_select_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t pool,
-                                   const float* d_floor, int64_t* d_out_rows, float* d_out_scores, void* stream) {
-    RR_REQUIRE(ix && d_queries && d_out_rows && d_out_scores, "rr_dense_select_dev: NULL argument");
+// phase 2 = selection / rescoring / ordering of the scan phase 1 left in `slot`, M-tiles opened no further down than `d_floor`.
+// `parts` (include/rr_hip.h): RR_SELECT_LIST | RR_SELECT_RESCORE | RR_SELECT_ORDER, each possibly on a stream of its own.
+extern "C" int rr_dense_select_part_dev(rr_index* ix, int32_t slot, int32_t parts, int32_t n_queries, int32_t pool,
+                                        const float* d_floor, int64_t* d_out_rows, float* d_out_scores, void* stream) {
+    RR_REQUIRE(ix, "rr_dense_select_dev: NULL handle");
+    RR_REQUIRE(parts >= 1 && parts <= 7, "rr_dense_select_dev: parts %d is not a combination of RR_SELECT_LIST | _RESCORE | _ORDER", parts);
+    RR_REQUIRE(!(parts & 4) || (d_out_rows && d_out_scores), "rr_dense_select_dev: NULL output");
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
-    int rc = rr_scratch_enter(ix, st);
+    int rc = rr_slot_activate(ix, slot);
     if (rc) return rc;
-    rc = rr_dense_chunk_flt(ix, ix->d_q, n_queries, pool, d_out_rows, d_out_scores, st, 2, 0, nullptr, d_floor);
-    RR_REQUIRE(rc != RR_FLT_SMALL, "rr_dense_select_dev: no scan of these %d queries (pool %d) is pending: call rr_dense_scan_dev "
-               "first and use its `applied` answer", n_queries, pool);
+    rc = rr_scratch_enter(ix, st, false, true);
     if (rc) return rc;
-    return rr_scratch_leave(ix, st);
+    rc = rr_dense_chunk_flt(ix, ix->d_q, n_queries, pool, d_out_rows, d_out_scores, st, 2, 0, nullptr, d_floor, parts);
+    RR_REQUIRE(rc != RR_FLT_SMALL, "rr_dense_select_dev: no scan of these %d queries (pool %d) is pending in slot %d: call "
+               "rr_dense_scan_dev first and use its `applied` answer", n_queries, pool, slot);
+    if (rc) return rc;
+    return rr_scratch_leave(ix, st, false, true);
+}
+
+extern "C" int rr_dense_select_slot_dev(rr_index* ix, int32_t slot, int32_t n_queries, int32_t pool, const float* d_floor,
+                                        int64_t* d_out_rows, float* d_out_scores, void* stream) {
+    return rr_dense_select_part_dev(ix, slot, 7, n_queries, pool, d_floor, d_out_rows, d_out_scores, stream);
+}
+
+extern "C" int rr_dense_scan_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t pool, int32_t kth,
+                                 float* d_bound, int32_t* applied, void* stream) {
+    RR_REQUIRE(kth >= 1 && d_bound, "rr_dense_scan_dev: kth %d out of [1, pool] / NULL bound", kth);
+    return rr_dense_scan_slot_dev(ix, 0, d_queries, n_queries, pool, kth, d_bound, applied, stream);
+}
+
+extern "C" int rr_dense_select_dev(rr_index* ix, const float* d_queries, int32_t n_queries, int32_t pool,
+                                   const float* d_floor, int64_t* d_out_rows, float* d_out_scores, void* stream) {
+    RR_REQUIRE(d_queries, "rr_dense_select_dev: NULL argument");
+    return rr_dense_select_slot_dev(ix, 0, n_queries, pool, d_floor, d_out_rows, d_out_scores, stream);
 }
 
 extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n_queries,
@@ -1522,6 +1612,8 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
+    int rc0 = rr_slot_activate(ix, 0);
+    if (rc0) return rc0;
     rr_flt_drop_pending(ix);
     // (the queries may sit in pinned host memory: rr_pad_queries then reads them over PCIe, once -- no copy command)
     const void* q_vis = nullptr;
@@ -1567,7 +1659,9 @@ extern "C" int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_que
     // device's default stream unless they say otherwise: use that stream here too so two host
     // threads (one on each entry point) stay ordered on the scratch.
     hipStream_t st = nullptr;
-    int rce = rr_scratch_enter(ix, st);
+    int rce = rr_slot_activate(ix, 0);
+    if (rce) return rce;
+    rce = rr_scratch_enter(ix, st);
     if (rce) return rce;
     const int slots = (int)rr_round_up(n_queries, RR_MFMA_MAXQ);   // kernels read whole query tiles
     RR_HIP_TRY(hipMemsetAsync(ix->d_q, 0, sizeof(float) * (size_t)slots * ix->dim_pad, st));

@@ -1112,112 +1112,159 @@ __global__ __launch_bounds__(256) void rr_flt_sigma(const float* __restrict__ sa
 }
 
 // ------------------------------------------------------------------ exact rescoring
-// One wave per (query, listed 8-row M-tile): the single-query scans' per-row arithmetic -- lane j of
-// a 16-lane row takes 16-byte units j, j + 16, ... of the row, one fmaf chain over its 24 elements in
-// ascending order, rr_row16_sum over the row (rr_scan_f32<6,1> / rr_scan_bf16<1>).  sc[query][slot][8].
+// The listed 8-row M-tiles of a query, rescored with the single-query scans' per-row arithmetic -- lane j of a 16-lane row
+// takes 16-byte units j, j + 16, ... of the row, one fmaf chain over its 24 elements in ascending order, rr_row16_sum over
+// the row (rr_scan_f32<6,1> / rr_scan_bf16<1>).  sc[query][slot][8].
+//
+// The kernel is a gather of ~500 scattered M-tiles per query (768 B per plane row): what it costs is how many bytes a
+// CU keeps in flight.  A wave therefore takes U M-tiles per pass and issues ALL their row loads before it looks at the
+// first (U x 2 x 3 loads of 16 B per lane); the query sits in LDS (no registers held for it).  On a stream masked to a
+// few CUs (the pipelined K1: this runs beside the next batch's scan) that is the difference between ~30 and ~90 GB/s
+// per CU.
+//
+// fp32 rows with a bf16 filter plane: a row is first scored on its plane row -- half the bytes -- as sum a~_k q_k, which
+// is within eps of its exact score (|sum (a~ - a) q| <= ||a - a~|| ||q||, plus the summation roundings the bound's 2^-14
+// term covers); the exact chain over the fp32 row runs only where that can reach the row cut tau (= key of tau~ - 1.02
+// eps): one row in eight of an opened M-tile, typically.  The others get -inf: they are below the cut whatever their
+// exact score is.  The rows that need the exact chain are taken per 16-lane group from a bit mask, one row per group and
+// round, so a round serves up to four rows of four different M-tiles.
+__device__ __forceinline__ float rr_bf16x8_chain(const u32x4 x, const f32x4 q0, const f32x4 q1, float acc) {
+    acc = __builtin_fmaf(__uint_as_float(x.x << 16), q0.x, acc);
+    acc = __builtin_fmaf(__uint_as_float(x.x & 0xFFFF0000u), q0.y, acc);
+    acc = __builtin_fmaf(__uint_as_float(x.y << 16), q0.z, acc);
+    acc = __builtin_fmaf(__uint_as_float(x.y & 0xFFFF0000u), q0.w, acc);
+    acc = __builtin_fmaf(__uint_as_float(x.z << 16), q1.x, acc);
+    acc = __builtin_fmaf(__uint_as_float(x.z & 0xFFFF0000u), q1.y, acc);
+    acc = __builtin_fmaf(__uint_as_float(x.w << 16), q1.z, acc);
+    acc = __builtin_fmaf(__uint_as_float(x.w & 0xFFFF0000u), q1.w, acc);
+    return acc;
+}
+
+#define RR_RESCORE_U 4            // M-tiles per wave and pass (bf16 rows / plane rows); fp32 rows without a plane: half
 template <bool A_BF16>
-__global__ __launch_bounds__(256) void rr_rescore_chain(
+__global__ __launch_bounds__(256, 3) void rr_rescore_chain(
     const void* __restrict__ mat, int64_t n_rows, const float* __restrict__ queries,   // [nq][384] fp32, padded
     const uint32_t* __restrict__ mtiles, const int32_t* __restrict__ count, const int32_t* __restrict__ fb,
-    float* __restrict__ sc,
-    // fp32 rows with a bf16 filter plane (null otherwise): a row is first scored on its plane row -- half the bytes --
-    // as sum a~_k q_k, which is within eps of its exact score (|sum (a~ - a) q| <= ||a - a~|| ||q||, plus the summation
-    // roundings the bound's 2^-14 term covers); the exact chain over the fp32 row runs only where that can reach the
-    // row cut tau (= key of tau~ - 1.02 eps): one row in eight of an opened M-tile, typically.  The others get -inf:
-    // they are below the cut whatever their exact score is.
-    const u32x4* __restrict__ plane_rows, const uint32_t* __restrict__ tau, const float* __restrict__ eps) {
+    float* __restrict__ sc, const u32x4* __restrict__ plane_rows,                      // (null: no plane)
+    const uint32_t* __restrict__ tau, const float* __restrict__ eps) {
+    __shared__ f32x4 qs[96];
     const int q = blockIdx.y;
     if (fb[q]) return;
     const int n = count[q];
-    const int lane = threadIdx.x & 63;
+    const bool planed = A_BF16 || plane_rows != nullptr;           // rows of 48 16-byte units go through the U-deep pass
+    const int per_wave = planed ? RR_RESCORE_U : RR_RESCORE_U / 2;
+    if ((int)blockIdx.x * 4 * per_wave >= n) return;               // (the whole workgroup: before the barrier)
+    if (threadIdx.x < 96) qs[threadIdx.x] = reinterpret_cast<const f32x4*>(queries + (int64_t)q * 384)[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & 15, grp = lane >> 4;
-    const f32x4* qv = reinterpret_cast<const f32x4*>(queries + (int64_t)q * 384);
-    float pre_thr = (!A_BF16 && plane_rows) ? rr_key2f(tau[q]) - 1.01f * eps[q] : -INFINITY;
-    if (!(pre_thr == pre_thr)) pre_thr = -INFINITY;           // (a key that is not a score, a NaN bound: every row takes the exact chain)
-    f32x4 qreg[6];
-    if (A_BF16) {
+    mtiles += (int64_t)q * RR_X3_MCAP;
+    sc += (int64_t)q * RR_X3_MCAP * 8;
+    const int64_t last_row = n_rows - 1;
+    if (planed) {
+        constexpr int U = RR_RESCORE_U;
+        const u32x4* rows16 = A_BF16 ? static_cast<const u32x4*>(mat) : plane_rows;
+        float pre_thr = A_BF16 ? -INFINITY : rr_key2f(tau[q]) - 1.01f * eps[q];
+        if (!(pre_thr == pre_thr)) pre_thr = -INFINITY;   // (a key that is not a score, a NaN bound: every row takes the exact chain)
+        for (int s0 = ((int)blockIdx.x * 4 + wave) * U; s0 < n; s0 += (int)gridDim.x * 4 * U) {
+            uint32_t m8[U];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            qreg[2 * i] = qv[2 * (sub + 16 * i)];
-            qreg[2 * i + 1] = qv[2 * (sub + 16 * i) + 1];
-        }
-    } else {
+            for (int u = 0; u < U; ++u) m8[u] = mtiles[s0 + u < n ? s0 + u : n - 1];      // (a repeated last tile: its stores are masked)
+            u32x4 x[U][2][3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) qreg[i] = qv[16 * i + sub];
-    }
-    f32x4 qpl[6];                                              // the query in the plane pre-scoring's lane order
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        qpl[2 * i] = (!A_BF16 && plane_rows) ? qv[2 * (sub + 16 * i)] : f32x4{0.f, 0.f, 0.f, 0.f};
-        qpl[2 * i + 1] = (!A_BF16 && plane_rows) ? qv[2 * (sub + 16 * i) + 1] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int slot = blockIdx.x * 4 + (threadIdx.x >> 6); slot < n; slot += gridDim.x * 4) {
-        const int64_t m8 = mtiles[(int64_t)q * RR_X3_MCAP + slot];
-        float mine = 0.f;
+                for (int it = 0; it < 2; ++it) {           // four rows per step: lane (sub, grp) -> row 4 it + grp
+                    int64_t row = (int64_t)m8[u] * 8 + 4 * it + grp;
+                    row = row < last_row ? row : last_row;
+                    const u32x4* pp = rows16 + row * 48 + sub;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {                   // four rows per step: lane (sub, grp) -> row 4 it + grp
-            int64_t row = m8 * 8 + 4 * it + grp;
-            row = row < n_rows ? row : n_rows - 1;
-            float acc = 0.f;
-            if (A_BF16) {
-                const u32x4* p = static_cast<const u32x4*>(mat) + row * 48 + sub;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const u32x4 x = p[16 * i];
-                    const f32x4 q0 = qreg[2 * i], q1 = qreg[2 * i + 1];
-                    acc = __builtin_fmaf(__uint_as_float(x.x << 16), q0.x, acc);
-                    acc = __builtin_fmaf(__uint_as_float(x.x & 0xFFFF0000u), q0.y, acc);
-                    acc = __builtin_fmaf(__uint_as_float(x.y << 16), q0.z, acc);
-                    acc = __builtin_fmaf(__uint_as_float(x.y & 0xFFFF0000u), q0.w, acc);
-                    acc = __builtin_fmaf(__uint_as_float(x.z << 16), q1.x, acc);
-                    acc = __builtin_fmaf(__uint_as_float(x.z & 0xFFFF0000u), q1.y, acc);
-                    acc = __builtin_fmaf(__uint_as_float(x.w << 16), q1.z, acc);
-                    acc = __builtin_fmaf(__uint_as_float(x.w & 0xFFFF0000u), q1.w, acc);
+                    for (int i = 0; i < 3; ++i) x[u][it][i] = pp[16 * i];
                 }
-            } else {
-                bool exact = true;
-                if (plane_rows) {
-                    // the plane row in 16-byte pieces (lane `sub`: units sub, sub + 16, sub + 32 = dims 8 (sub + 16 i) .. + 7,
-                    // the query's values for them in qpl): three loads of 1 KiB per wave instead of six of 512 B.  Only a
-                    // filter (within eps of the exact score in any summation order): the exact chain below decides.
-                    const u32x4* pp = plane_rows + row * 48 + sub;
+            uint32_t need = 0;                             // bit 2 u + it: that row of this 16-lane group takes the exact chain
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
                     float est = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const u32x4 x = pp[16 * i];
-                        const f32x4 q0 = qpl[2 * i], q1 = qpl[2 * i + 1];
-                        est = __builtin_fmaf(__uint_as_float(x.x << 16), q0.x, est);
-                        est = __builtin_fmaf(__uint_as_float(x.x & 0xFFFF0000u), q0.y, est);
-                        est = __builtin_fmaf(__uint_as_float(x.y << 16), q0.z, est);
-                        est = __builtin_fmaf(__uint_as_float(x.y & 0xFFFF0000u), q0.w, est);
-                        est = __builtin_fmaf(__uint_as_float(x.z << 16), q1.x, est);
-                        est = __builtin_fmaf(__uint_as_float(x.z & 0xFFFF0000u), q1.y, est);
-                        est = __builtin_fmaf(__uint_as_float(x.w << 16), q1.z, est);
-                        est = __builtin_fmaf(__uint_as_float(x.w & 0xFFFF0000u), q1.w, est);
-                    }
+                    for (int i = 0; i < 3; ++i)            // lane `sub`: units sub + 16 i = dims 8 (sub + 16 i) .. + 7
+                        est = rr_bf16x8_chain(x[u][it][i], qs[2 * (sub + 16 * i)], qs[2 * (sub + 16 * i) + 1], est);
                     est = rr_row16_sum(est);
-                    exact = est >= pre_thr || !(est == est);          // (the 16 lanes of a row agree; NaN: let the exact chain decide)
+                    const int64_t row = (int64_t)m8[u] * 8 + 4 * it + grp;
+                    const bool live = s0 + u < n;
+                    if (A_BF16) {                          // a bf16 index: that WAS the row's chain
+                        if (sub == 0 && live) sc[(int64_t)(s0 + u) * 8 + 4 * it + grp] = (row < n_rows && est == est) ? est : -INFINITY;
+                    } else {
+                        const bool exact = live && row < n_rows && (est >= pre_thr || !(est == est));   // (the 16 lanes of a row agree; NaN: the exact chain decides)
+                        need |= exact ? 1u << (2 * u + it) : 0u;
+                        if (sub == 0 && live && !exact) sc[(int64_t)(s0 + u) * 8 + 4 * it + grp] = -INFINITY;
+                    }
                 }
-                if (exact) {
+            if (!A_BF16) {
+                while (__any(need != 0u)) {
+                    if (need != 0u) {
+                        const int j = __ffs(need) - 1;
+                        need &= need - 1u;
+                        const int u = j >> 1, it = j & 1;
+                        uint32_t m = m8[0];
+#pragma unroll
+                        for (int v = 1; v < U; ++v) m = u == v ? m8[v] : m;
+                        const int64_t row = (int64_t)m * 8 + 4 * it + grp;
+                        const f32x4* p = static_cast<const f32x4*>(mat) + row * 96 + sub;
+                        f32x4 y[6];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) y[i] = p[16 * i];
+                        float acc = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            const f32x4 qq = qs[16 * i + sub];
+                            acc = __builtin_fmaf(y[i].x, qq.x, acc);
+                            acc = __builtin_fmaf(y[i].y, qq.y, acc);
+                            acc = __builtin_fmaf(y[i].z, qq.z, acc);
+                            acc = __builtin_fmaf(y[i].w, qq.w, acc);
+                        }
+                        acc = rr_row16_sum(acc);
+                        if (sub == 0) sc[(int64_t)(s0 + u) * 8 + 4 * it + grp] = acc == acc ? acc : -INFINITY;   // NaN scores rank last
+                    }
+                }
+            }
+        }
+    } else {
+        // fp32 rows, no plane (RR_NO_SHADOW / no room for it): every row takes the exact chain, two M-tiles' loads in flight
+        constexpr int U = RR_RESCORE_U / 2;
+        for (int s0 = ((int)blockIdx.x * 4 + wave) * U; s0 < n; s0 += (int)gridDim.x * 4 * U) {
+            uint32_t m8[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) m8[u] = mtiles[s0 + u < n ? s0 + u : n - 1];
+            f32x4 y[U][2][6];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    int64_t row = (int64_t)m8[u] * 8 + 4 * it + grp;
+                    row = row < last_row ? row : last_row;
                     const f32x4* p = static_cast<const f32x4*>(mat) + row * 96 + sub;
 #pragma unroll
+                    for (int i = 0; i < 6; ++i) y[u][it][i] = p[16 * i];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    float acc = 0.f;
+#pragma unroll
                     for (int i = 0; i < 6; ++i) {
-                        const f32x4 x = p[16 * i];
-                        acc = __builtin_fmaf(x.x, qreg[i].x, acc);
-                        acc = __builtin_fmaf(x.y, qreg[i].y, acc);
-                        acc = __builtin_fmaf(x.z, qreg[i].z, acc);
-                        acc = __builtin_fmaf(x.w, qreg[i].w, acc);
+                        const f32x4 qq = qs[16 * i + sub];
+                        acc = __builtin_fmaf(y[u][it][i].x, qq.x, acc);
+                        acc = __builtin_fmaf(y[u][it][i].y, qq.y, acc);
+                        acc = __builtin_fmaf(y[u][it][i].z, qq.z, acc);
+                        acc = __builtin_fmaf(y[u][it][i].w, qq.w, acc);
                     }
-                } else acc = -INFINITY;
-            }
-            acc = rr_row16_sum(acc);
-            mine = (sub == it) ? acc : mine;               // lane (sub, grp) keeps row 4 sub + grp (sub < 2)
-        }
-        if (sub < 2) {
-            const int r = 4 * sub + grp;
-            const int64_t row = m8 * 8 + r;
-            const float v = (row < n_rows && mine == mine) ? mine : -INFINITY;   // NaN scores and pad rows rank last
-            sc[((int64_t)q * RR_X3_MCAP + slot) * 8 + r] = v;
+                    acc = rr_row16_sum(acc);
+                    const int64_t row = (int64_t)m8[u] * 8 + 4 * it + grp;
+                    if (sub == 0 && s0 + u < n) sc[(int64_t)(s0 + u) * 8 + 4 * it + grp] = (row < n_rows && acc == acc) ? acc : -INFINITY;
+                }
         }
     }
 }
@@ -1389,19 +1436,24 @@ static int rr_flt_scan_set(rr_index* ix, int set, const rr_scan_geom& G, const v
 // selection + rescoring + ordering + per-64 fallback over nq_a (+ nq_b) queries of one (two) scan launches
 template <bool ROWS_BF16>
 static int rr_flt_finish(rr_index* ix, const rr_scan_geom& G, const float* d_q, int nq_a, int nq_b, int pool,
-                         int64_t* d_rows, float* d_scores, const float* sigma, hipStream_t st, const float* floor = nullptr) {
+                         int64_t* d_rows, float* d_scores, const float* sigma, hipStream_t st, const float* floor = nullptr,
+                         int parts = 7) {
     const rr_x3_scratch X = rr_x3_scratch_of(ix);
     const int nq = nq_a + nq_b;
-    rr_launch_select_mtiles(ix, G, nq_a, pool, st, X.eps, sigma, nq_b, rr_flt_mmax_set_stride(G), rr_flt_smax_set_stride(), floor);
+    if (parts & 1)
+        rr_launch_select_mtiles(ix, G, nq_a, pool, st, X.eps, sigma, nq_b, rr_flt_mmax_set_stride(G), rr_flt_smax_set_stride(), floor);
     // (the plane pre-scoring of the rescored rows: fp32 storage with a valid plane.  Under a corpus-wide floor the row cut is
     //  the floor: rows below it come back as -inf and only fill the shard's list up -- the merge never takes them)
     static const bool no_pre = getenv("RR_NO_RESCORE_PLANE") != nullptr;
     const u32x4* plane_rows = (!ROWS_BF16 && ix->shadow_valid && ix->d_shadow && !no_pre)
                                   ? reinterpret_cast<const u32x4*>(ix->d_shadow) : nullptr;
-    // (four M-tiles per workgroup and pass; under a corpus-wide floor a shard opens ~pool / 8 M-tiles per query: a quarter of the
-    //  workgroups -- 24 k fewer empty ones to dispatch per call)
-    hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(floor ? 32 : 128, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
-                       X.mtiles, X.count, X.fb, X.sc, plane_rows, X.tau, X.eps);
+    // (16 M-tiles per workgroup and pass, ~500-650 listed per query: up to 3 passes; under a corpus-wide floor a shard opens
+    //  ~pool / 8 M-tiles per query: a quarter of the workgroups.  Workgroups with nothing to do return before their barrier.)
+    if (parts & 2)
+        hipLaunchKernelGGL((rr_rescore_chain<ROWS_BF16>), dim3(floor ? 4 : 16, nq), dim3(256), 0, st, ix->d_matrix, G.n_rows, d_q,
+                           X.mtiles, X.count, X.fb, X.sc, plane_rows, X.tau, X.eps);
+    RR_HIP_TRY(hipGetLastError());
+    if (!(parts & 4)) return RR_OK;
     rr_launch_select_rescored(ix, G, nq, pool, d_rows, d_scores, st, floor != nullptr);
     RR_HIP_TRY(hipGetLastError());
     // Flagged queries: at most eight in the call -> the single-query chain (bit for bit a batch of one); more -> the stored-score
@@ -1444,7 +1496,8 @@ static int rr_flt_after_scan(rr_index* ix, const rr_scan_geom& G, const float* d
     rr_flt_pending* p = rr_flt_pending_of(ix);
     if (!p) return RR_E_HIP;
     *p = rr_flt_pending{true, G, d_q, nq_a, nq_b, pool, sigma, ROWS_BF16};
-    rr_launch_group_kth(ix, G, nq_a, nq_b, ph.kth, rr_x3_scratch_of(ix).eps, ph.d_bound, rr_flt_smax_set_stride(), st);
+    if (ph.kth > 0 && ph.d_bound)     // (kth = 0: the pipelined single-GPU K1 wants the split, not a bound)
+        rr_launch_group_kth(ix, G, nq_a, nq_b, ph.kth, rr_x3_scratch_of(ix).eps, ph.d_bound, rr_flt_smax_set_stride(), st);
     RR_HIP_TRY(hipGetLastError());
     return RR_OK;
 }
@@ -1547,16 +1600,16 @@ struct rr_flt_fresh_guard {
 };
 
 int rr_dense_chunk_flt(rr_index* ix, const float* d_q, int nq, int pool, int64_t* d_rows,
-                       float* d_scores, hipStream_t st, int phase, int kth, float* d_bound, const float* d_floor) {
+                       float* d_scores, hipStream_t st, int phase, int kth, float* d_bound, const float* d_floor, int parts) {
     rr_flt_fresh_guard fresh_guard{ix};
     if (d_q != ix->d_q) ix->flt_prep_fresh = false;       // a later chunk of a long call: its planes are not the prepared ones
     if (phase == 2) {
         // selection of the scan a phase-1 call left behind (same queries, same pool), with the exchanged floor
         rr_flt_pending* p = rr_flt_pending_of(ix);
         if (!p || !p->valid || p->nq_a + p->nq_b != nq || p->pool != pool || p->d_q != d_q) return RR_FLT_SMALL;   // (caller: plain call)
-        p->valid = false;
-        return p->rows_bf16 ? rr_flt_finish<true>(ix, p->G, d_q, p->nq_a, p->nq_b, pool, d_rows, d_scores, p->sigma, st, d_floor)
-                            : rr_flt_finish<false>(ix, p->G, d_q, p->nq_a, p->nq_b, pool, d_rows, d_scores, p->sigma, st, d_floor);
+        if (parts & 4) p->valid = false;
+        return p->rows_bf16 ? rr_flt_finish<true>(ix, p->G, d_q, p->nq_a, p->nq_b, pool, d_rows, d_scores, p->sigma, st, d_floor, parts)
+                            : rr_flt_finish<false>(ix, p->G, d_q, p->nq_a, p->nq_b, pool, d_rows, d_scores, p->sigma, st, d_floor, parts);
     }
     rr_flt_phase ph;
     ph.phase = phase;

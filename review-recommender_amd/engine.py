@@ -189,6 +189,40 @@ class HybridSearcher:
                                                 C.c_void_p(dense.data_ptr()), self._stream()), "rr_dense_select_dev")
         return rows, dense
 
+    def dense_scan_slot(self, slot: int, q_dev, pool: int, kth: int = 0):
+        """Phase 1 of the pipelined K1 (rr_dense_scan_slot_dev) on the CURRENT stream: the scan of ``q_dev`` into scan slot
+        ``slot`` (0 / 1).  ``kth`` > 0 (row shards): also the per-query bound of dense_scan, returned as a float32 (B,)
+        tensor; ``kth`` = 0: returns True.  None when the call cannot be split (then use dense_pool)."""
+        torch = _torch()
+        B = q_dev.shape[0]
+        bound = torch.empty((B,), dtype=torch.float32, device=self.device) if kth > 0 else None
+        applied = C.c_int32(0)
+        _lib.check(self.lib.rr_dense_scan_slot_dev(self.index.handle, int(slot), C.c_void_p(q_dev.data_ptr()), B, pool, int(kth),
+                                                   C.c_void_p(bound.data_ptr()) if kth > 0 else None, C.byref(applied),
+                                                   self._stream()), "rr_dense_scan_slot_dev")
+        if not applied.value:
+            return None
+        return bound if kth > 0 else True
+
+    SELECT_LIST, SELECT_RESCORE, SELECT_ORDER = 1, 2, 4        # include/rr_hip.h: RR_SELECT_*
+
+    def dense_select_slot(self, slot: int, B: int, pool: int, floor=None, out=None, parts: int = 7):
+        """Phase 2 (rr_dense_select_part_dev) on the CURRENT stream -- which may be another one than the scan's, and another
+        one per part (SELECT_LIST | SELECT_RESCORE | SELECT_ORDER): the library orders them with events.  Returns
+        (rows, dense) when SELECT_ORDER is among the parts, else None."""
+        torch = _torch()
+        rows = dense = None
+        if parts & self.SELECT_ORDER:
+            if out is not None:
+                rows, dense = out
+            else:
+                rows = torch.empty((B, pool), dtype=torch.int64, device=self.device)
+                dense = torch.empty((B, pool), dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(self.lib.rr_dense_select_part_dev(self.index.handle, int(slot), int(parts), B, pool, p(floor), p(rows), p(dense),
+                                                     self._stream()), "rr_dense_select_part_dev")
+        return (rows, dense) if parts & self.SELECT_ORDER else None
+
     def bm25_at(self, term_id_lists: Sequence[Sequence[int]], rows_dev, mode: str = "forward", out=None):
         """K2 on device tensors: float32 (B, pool) raw BM25 at the candidate rows."""
         torch = _torch()

@@ -36,3 +36,25 @@ def assert_topk_matches(rows, scores, ref_sims64, k, tie_eps=4e-7, score_tol=1e-
 def min_gap(ref_sims64, k):
     top = np.sort(ref_sims64)[::-1][:k + 1]
     return float(np.min(-np.diff(top))) if len(top) > 1 else float("inf")
+
+
+def assert_ranking_matches(got_ids, want_ids, want_final, band, pool_ids=None, pool_final=None):
+    """Ranked ids against the oracle's ranking, compared PER TIE BAND: consecutive oracle entries whose finals differ by at
+    most ``band`` (twice the score tolerance: two scores each within tol may swap) form a band, inside which the order is
+    free and outside which it is exact.  A band cut off by k may also hold other candidates of the oracle's pool
+    (``pool_ids`` / ``pool_final``) whose final is within ``band`` of the band's."""
+    got_ids, want_ids = list(got_ids), list(want_ids)
+    wf = np.asarray(want_final, dtype=np.float64)
+    assert len(got_ids) == len(want_ids) == len(wf)
+    i, n = 0, len(want_ids)
+    while i < n:
+        j = i + 1
+        while j < n and abs(wf[j - 1] - wf[j]) <= band:
+            j += 1
+        if j == n and pool_ids is not None:
+            pf = np.asarray(pool_final, dtype=np.float64)
+            allowed = {p for p, f in zip(pool_ids, pf) if wf[j - 1] - band <= f <= wf[i] + band}
+            assert set(got_ids[i:j]) <= allowed | set(want_ids[i:j]), (i, j)
+        else:
+            assert set(got_ids[i:j]) == set(want_ids[i:j]), f"ranks {i}..{j - 1}: {got_ids[i:j]} vs {want_ids[i:j]}"
+        i = j

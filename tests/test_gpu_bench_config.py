@@ -104,17 +104,100 @@ def test_one_bench_step_at_1M_products_matches_the_oracle(shard):
     check_one_bench_step(sh, a, DOCS, (0, 17, 101, 255))
 
 
-def test_one_bench_step_at_10M_products_matches_the_oracle():
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_one_bench_step_at_10M_products_matches_the_oracle(dtype):
     """The headline configuration itself (BASELINE metric: 10M products, hybrid alpha = 0.5, k = 100, batches of 256):
     bench.py's own builder at its default size, one whole step checked by properties for every query and against the
-    oracle pipeline for one sampled query of each query set of the scan launch."""
+    oracle pipeline for one sampled query of each query set of the scan launch.
+    dtype "bf16" = BASELINE config 4's storage (10M x 384 bf16, batch 256) on the one GPU there is: the oracle is the
+    fp32 pipeline over the bf16-rounded matrix upcast to fp32; config 4's row sharding itself is covered by
+    tests/test_gpu_sharded.py (bitwise = unsharded) and tests/test_sharded_gloo.py."""
     dev = torch.device("cuda", 0)
     docs = 10_000_000
-    sh = build_device_shard(torch, None, docs=docs, rank=0, world=1, dev=dev, vocab=VOCAB, doc_len=40)
+    sh = build_device_shard(torch, None, docs=docs, rank=0, world=1, dev=dev, vocab=VOCAB, doc_len=40, dtype=dtype)
     a = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in sh.bm25_arrays.items()}
-    check_one_bench_step(sh, a, docs, (17, 201))
+    check_one_bench_step(sh, a, docs, (17, 201) if dtype == "f32" else (201,))
     info = sh.index.last_scan_info()
     assert info[0] == 5 and info[1] == 9 and info[2] == 256, info      # the 256-query launch bench.py's roofline names
+    assert info[4] == 2                                                 # a bf16 stream: the filter plane / the bf16 rows
+    sh.index.close()
+    del sh, a
+    torch.cuda.empty_cache()
+
+
+def synthetic_pair_tokens(b, rows):
+    """bench.SyntheticPairScorer's token recipe in numpy: the packed [CLS] q [SEP] text [SEP] ids of (query b, product row)."""
+    out = []
+    for r in rows:
+        r = int(r)
+        ln = 54 + (r * 2654435761 % 448) + 11
+        pos = np.arange(ln, dtype=np.int64)
+        hq = (b * 40503 + pos * 9973) % 29000 + 1000
+        ht = (r * 7919 + pos * 104729) % 29000 + 1000
+        tok = np.where(pos == 0, 101, np.where(pos <= 8, hq, np.where((pos == 9) | (pos == ln - 1), 102, ht)))
+        out.append((tok.astype(np.int32), (pos > 9).astype(np.int32)))
+    return out
+
+
+def test_config5_step_matches_the_oracle(shard):
+    """BASELINE config 5's step on one GPU: bench.py's builder (1M products here), batch 64, hybrid + cross-encoder rerank
+    of the first 200 pool rows -> top 20, the K5 kernels in the reference's precision (fp32) over bench.py's own
+    SyntheticPairScorer.  Properties for all 64 queries; for ONE sampled query the numpy oracle (oracle/cross_encoder.py)
+    scores its 200 pairs and the oracle pipeline fuses them: skus identical (per tie band), `_final` within 1e-5."""
+    import bench
+    from oracle.cross_encoder import predict_oracle
+    from parity import assert_ranking_matches
+    sh, a = shard
+    B, K5, RR, PL = 64, 20, 200, 200
+    dev = torch.device("cuda", 0)
+    scorer = bench.SyntheticPairScorer(torch, dev, seed=7, precision="fp32")
+    w = FusionWeights(w_dense=0.4, w_bm25=0.2, w_rerank=0.3, w_prior=0.1, w_best=0.0, gate_penalty=1.0)    # bench.py --rerank-k
+    Q = synth.unit_rows(B, 384, 4321)
+    terms = synth.query_terms(B, VOCAB, 99, sh.stats["df"])
+    q_dev = torch.from_numpy(Q).cuda()
+    rows, cols, order = [t.cpu().numpy() for t in
+                         sh.sharded.search_batch_dev(q_dev, terms, K5, w, rerank_k=RR, rerank_fn=scorer)]
+    assert rows.shape == (B, PL) and cols.shape == (B, 8, PL) and order.shape == (B, K5)
+    assert scorer.pairs == B * RR and 65 * scorer.pairs <= scorer.tokens <= 512 * scorer.pairs
+    rr_n, final = cols[:, 3], cols[:, 7]
+    assert np.all((rows >= 0) & (rows < DOCS)) and all(len(set(r.tolist())) == PL for r in rows)
+    assert np.all(rr_n.max(axis=1) == 1.0) and np.all(rr_n.min(axis=1) == 0.0)          # min-max of 200 distinct logits
+    top_final = np.take_along_axis(final, order.astype(np.int64), axis=1)
+    assert np.all(np.diff(top_final, axis=1) <= 0) and all(len(set(o.tolist())) == K5 for o in order)
+    rest = np.ones((B, PL), bool)
+    np.put_along_axis(rest, order.astype(np.int64), False, axis=1)
+    assert np.all(np.where(rest, final, -1).max(axis=1) <= top_final[:, -1])
+
+    # one sampled query against the oracle: numpy BERT on its 200 pairs, the reference's pipeline around it
+    b = 41
+    V = sh.matrix.cpu().numpy()
+    ora = BM25CsrOracle(a["post_indptr"], a["post_docs"], a["post_tf"], a["doc_len"], a["idf"], a["avgdl"])
+    s = sh.sharded.s
+    n_out, s_out, l_out = (torch.empty(DOCS, dtype=torch.float64, device="cuda") for _ in range(3))
+    all_rows = torch.arange(DOCS, dtype=torch.int64, device="cuda")
+    _lib.check(s.lib.rr_index_gather_meta_dev(s.index.handle, C.c_void_p(all_rows.data_ptr()), DOCS,
+                                              C.c_void_p(n_out.data_ptr()), C.c_void_p(s_out.data_ptr()),
+                                              C.c_void_p(l_out.data_ptr()), s._stream()), "gather_meta")
+    torch.cuda.synchronize()
+    skus = synth.skus(DOCS)
+    # (the synthetic products have no text: the product's ROW stands in for it, which is what the token recipe hashes)
+    meta = pd.DataFrame({"sku": skus, "n_reviews": n_out.cpu().numpy(), "avg_stars": s_out.cpu().numpy(),
+                         "agg_text": [str(i) for i in range(DOCS)]})
+    sd = synth.bert_state_dict(7, n_layers=6, n_labels=1)
+    rerank = lambda pairs: predict_oracle(sd, synthetic_pair_tokens(b, [int(t) for _, t in pairs]), n_layers=6)
+    query = " ".join(f"t{int(t)}" for t in terms[b])
+    want, _, dbg, cand = run_search_oracle(query=query, qvec=Q[b], meta=meta, V=V, bm25=_IdTokenBM25(ora), bm25_skus=skus,
+                                           k=K5, rerank_k=RR, w_dense=0.4, w_bm25=0.2, w_rerank=0.3, w_prior=0.1,
+                                           w_best=0.0, prior_C=20.0, min_reviews=8, gate_penalty=1.0, rerank_fn=rerank)
+    assert dbg["pool"] == PL
+    got_rows = rows[b][order[b]]
+    np.testing.assert_allclose(top_final[b], want["_final"].values, atol=1e-5, rtol=0)
+    assert_ranking_matches(got_rows.tolist(), want["_row"].tolist(), want["_final"].values, 2e-5,
+                           cand["_row"].tolist(), cand["_final"].values)
+    # the rerank column of the pool, against the oracle's (min-max stretches the logits' error by 1 / span)
+    pos = {int(r): j for j, r in enumerate(cand["_row"].values)}
+    idx = [pos[int(r)] for r in rows[b]]
+    assert np.abs(cols[b, 3] - cand["_rerank"].values[idx]).max() < 2e-5
 
 
 def check_one_bench_step(sh, a, DOCS, samples):
@@ -141,7 +224,7 @@ def check_one_bench_step(sh, a, DOCS, samples):
     assert np.array_equal(again[0], rows) and np.array_equal(again[1], cols) and np.array_equal(again[2], order)
 
     # sampled queries against the oracle pipeline (reference semantics: sku dict over all N, app flavour)
-    V = sh.matrix.cpu().numpy()
+    V = sh.matrix.float().cpu().numpy()                      # (bf16 storage: the rounded matrix upcast to fp32)
     ora = BM25CsrOracle(a["post_indptr"], a["post_docs"], a["post_tf"], a["doc_len"], a["idf"], a["avgdl"])
     # metadata as the builder generated it: re-derive from the device index through K3's own gather
     n_out = torch.empty(DOCS, dtype=torch.float64, device="cuda")

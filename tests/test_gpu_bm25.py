@@ -92,3 +92,25 @@ def test_queries_of_any_length_are_scored_in_64_token_passes():
         want = ora.get_scores(q.tolist())[rows[0]].astype(np.float32)
         for mode in ("forward", "postings"):
             assert np.array_equal(dev.scores_at_ids([q], rows, mode)[0], want), (n_tok, mode)
+
+
+def test_get_scores_writes_only_the_slices_it_touches_and_stays_exact_call_after_call():
+    """rr_bm25_slices keeps its N-double result array all-zero between calls and writes a 4096-document slice only when a
+    token has a posting there (or the previous call left something): a head-term query, then a rare-term query whose
+    postings sit in a few slices, then nothing, then a 40-token query (blocks are located 16 tokens at a time, with a
+    duplicate and unknown ids) -- every answer bit for bit the oracle's, whatever the call before it left behind."""
+    n, vocab = 300_000, 50_000
+    ip, terms, tf, dl = synth.bm25_forward_csr(n, vocab, 40, 31)
+    corpus = BM25Corpus(ip, terms, tf, dl, vocab)
+    dev = corpus.to_device()
+    ora = csr_oracle(corpus)
+    df = np.bincount(terms, minlength=vocab)
+    rare = np.flatnonzero((df >= 1) & (df <= 3))[:2].astype(np.int32)
+    head = np.argsort(-df)[:3].astype(np.int32)
+    rng = np.random.default_rng(2)
+    long_q = np.concatenate([rng.integers(-1, vocab, 38), head[:1], head[:1]]).astype(np.int32)
+    for q in (head, rare, np.zeros(0, np.int32), long_q, rare[:1], head, np.array([-1, vocab + 5], np.int32)):
+        got = dev.get_scores_ids(q)
+        want = ora.get_scores([int(t) for t in q if 0 <= t < vocab])     # (unknown ids add +0.0: idf.get -> 0)
+        assert got.dtype == np.float64 and np.array_equal(got, want), q[:4]
+    assert np.count_nonzero(dev.get_scores_ids(rare)) == int(np.count_nonzero(ora.get_scores(rare.tolist()))) <= 6
