@@ -333,12 +333,16 @@ def main():
     # Every batch is still submitted AND finished inside the timed region (drain() in front of the closing fence).
     pipelined = ((world > 1 or args.force_payload) and args.rerank_k == 0 and one_stream and kernel_copies
                  and os.environ.get("RR_BENCH_NO_PIPELINE") is None)
-    inflight = [None]
+    # RR_TAIL_OVERLAP_CUS=n (A/B; off by default: measured slower, profiles/r04_overlap_ab.md): submit / finish become a
+    # three-stage pipeline on two CU-masked streams -- scan(i + 1) on n CUs | selection + K2 + payload all-gather(i) | merge +
+    # K3(i - 1) on the rest -- and two batches stay in flight behind the one being submitted.
+    overlap = pipelined and sharded.enable_overlap()
+    depth = 2 if overlap else 1
+    inflight = []
 
-    def drain():
-        if inflight[0] is not None:
-            rows, cols, order = sharded.finish(inflight[0])
-            inflight[0] = None
+    def drain(keep=0):
+        while len(inflight) > keep:
+            rows, cols, order = sharded.finish(inflight.pop(0))
             p_rows, p_order, p_final = pins[0]
             sharded.s.copy_segments([(p_rows, rows), (p_order, order), (p_final, cols[:, 7, :])])
 
@@ -347,8 +351,8 @@ def main():
         cur = torch.cuda.current_stream(dev)
         if pipelined:
             t = sharded.submit(q_pin, terms, args.k, w)
-            drain()
-            inflight[0] = t
+            drain(depth - 1)
+            inflight.append(t)
             return
         if one_stream and kernel_copies:
             # H2D: K1's first kernel reads the pinned query vectors over PCIe itself; the token ids go through the
@@ -505,23 +509,26 @@ def main():
         bytes_per_launch = n_local * DIM * info["elem_bytes"]      # what the batched scan streams once per launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         qpl, terms_per_dim = info["queries_per_launch"], info["mfma_terms"]
-        # HBM traffic per launch from the PMC passes kept in profiles/ (FETCH_SIZE / WRITE_SIZE collected and
-        # corrected as MI355X_MICROARCH.md prescribes), for this kernel at this many queries per launch on 10M
-        # rows; the same bytes-per-row ratio is applied to this run's rows.  null without such a summary.
-        traffic = None
+        # HBM traffic per launch: NOT measured in this run -- replayed from the PMC passes kept in profiles/ (FETCH_SIZE /
+        # WRITE_SIZE collected and corrected as MI355X_MICROARCH.md prescribes, tools/profile_pmc.sh) for this kernel at this
+        # many queries per launch on 10M rows, the same bytes-per-row ratio applied to this run's rows.  The line says so:
+        # `traffic` stays null (nothing was counted here), `traffic_from_profile` carries the figure and its file.
+        traffic_from_profile = None
         # (r03: the 256-query rr_scan_fltq on 16x16x32 MFMAs; r02: the 128-query scan over the bf16 filter plane with the store
         #  prefilter; r01: the same scan over fp32 rows -- the newest summary of this launch shape wins)
-        for tag in (("r03", "r02") if info["elem_bytes"] == 2 else ("r01",)):
+        for tag in (("r04", "r03", "r02") if info["elem_bytes"] == 2 else ("r01",)):
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_scan_b{qpl}_10M.json")
             if os.path.exists(pmc) and args.dtype == "f32":
                 with open(pmc) as f:
                     m = json.load(f)
-                traffic = int(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"] * bytes_per_launch)
+                traffic_from_profile = {"bytes": int(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"] * bytes_per_launch),
+                                        "ratio_to_algorithmic": round(m["hbm_bytes_per_launch"] / m["algorithmic_bytes_per_launch"], 4),
+                                        "file": os.path.relpath(pmc, ROOT)}
                 break
         pf = terms_per_dim * 2.0 * n_local * DIM * qpl / (avg_ms * 1e-3) / 1e15 if launches else 0.0
         hbm_frac, mfma_frac = achieved / HBM_PEAK_GBS, pf / BF16_MFMA_PEAK_PF
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(hbm_frac, 4), "traffic": traffic, "kernel": info["kernel"],
+                "frac": round(hbm_frac, 4), "traffic": None, "traffic_from_profile": traffic_from_profile, "kernel": info["kernel"],
                 "launches": int(launches), "avg_launch_ms": round(avg_ms, 5), "bytes_per_launch": bytes_per_launch,
                 "queries_per_launch": qpl, "launches_per_step": round(launches / max(args.steps, 1), 3)}
         if terms_per_dim:
@@ -551,10 +558,14 @@ def main():
                                        f"({stats['nnz']} postings on rank 0, {stats.get('sum_df_per_query', 0):.0f} "
                                        f"postings per query)" if not args.no_bm25 else "")
                                     + f", batches of {args.batch} queries"),
+                       # four seeded query sets are cycled (step i searches set i % 4): the library keeps nothing between calls
+                       # (tests: "the same batch again gives the same bits", token lists staged on every call)
+                       "query_sets": len(qsets),
                        "docs": args.docs, "docs_per_gpu": n_local, "batch": args.batch, "k": args.k,
                        "pool": pool, "parallelism": ("single GPU: no collective" if world == 1 else
                                                        f"row-shard x{world} + 1 all-reduce(min, B floats) + 1 all-gather"
-                                                       + (" started under the next batch's K1" if pipelined else ""))},
+                                                       + (" started under the next batch's K1" if pipelined else "")
+                                                       + (f"; every batch's tail on {torch.cuda.get_device_properties(dev).multi_processor_count - sharded._ov.scan_cus} CUs beside the next batch's scan on {sharded._ov.scan_cus}" if overlap else ""))},
             "roofline": roof,
             # the single-query scan on the same shard: the HBM-bound end of the same path
             "roofline_single_query": single,
@@ -569,6 +580,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and rerank_fn is None:
             out["cpu_baseline"] = cpu_baseline(torch, args, shard, qsets)
         print(json.dumps(out), flush=True)
+    if overlap:
+        sharded.disable_overlap()          # (the CU-masked streams are destroyed before the process ends)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -51,6 +51,9 @@ def parse_args(argv=None):
                          "runs on the GPU (csrc/rr_ce.hip); nothing is fetched")
     ap.add_argument("--rerank-model-dir", type=str, default=os.environ.get("RERANK_MODEL_DIR", ""),
                     help="local Hugging Face directory of the cross-encoder reranker, likewise")
+    ap.add_argument("--ce-precision", choices=["fp32", "bf16"], default="fp32",
+                    help="arithmetic of the two GPU encoders: fp32 = the reference's (logits / embeddings within 1e-5 of "
+                         "transformers; ~6x the time of bf16), bf16 = the fast path (2.5e-2 on logits)")
     ap.add_argument("--allow-hub", action="store_true",
                     help="opt in to sentence-transformers by model name (EMB_MODEL / RERANK_MODEL, app/test.py:28-29) for "
                          "whatever model no local directory was given; off by default: the product path is the GPU one")
@@ -65,10 +68,10 @@ def _load_encoders(args=None):
     if args is not None and (args.emb_model_dir or args.rerank_model_dir):
         from .cross_encoder import CrossEncoder, QueryEncoder
         if args.emb_model_dir:
-            enc = QueryEncoder.from_pretrained_dir(args.emb_model_dir, device=args.device)
+            enc = QueryEncoder.from_pretrained_dir(args.emb_model_dir, device=args.device, precision=args.ce_precision)
         if args.rerank_model_dir:
             try:
-                ce = CrossEncoder.from_pretrained_dir(args.rerank_model_dir, device=args.device)
+                ce = CrossEncoder.from_pretrained_dir(args.rerank_model_dir, device=args.device, precision=args.ce_precision)
             except Exception as e:   # app/test.py:220-222
                 print(f"[warn] cross-encoder load failed: {e}; skipping reranker.", flush=True)
     if args is None or not args.allow_hub:

@@ -248,6 +248,9 @@ def emit_loop(abl=0):
     if abl >= 1024:
         ABL = 0
     S = Stream()
+    # m0 is rewritten for every LDS-DMA piece below.  The compiler ignores a clobber of that reserved register ("may not be
+    # preserved"), and its own LDS-DMA code in the C++ bodies around this statement may keep a value in it: saved and restored
+    S.raw("s_mov_b32 %[m0s], m0", 0)
     S.raw("L_fltq_loop_%=:", 0)
     for k in range(4):
         gen_body(S, k)
@@ -258,11 +261,13 @@ def emit_loop(abl=0):
     # that an MFMA wrote them 32 cycles ago: let the matrix pipe drain here
     S.raw("s_nop 15", 16)
     S.raw("s_nop 7", 8)
+    S.raw("s_mov_b32 m0, %[m0s]", 0)
     out = []
     out.append("{")
     out.append("    u32x4 " + ", ".join(f"tA{i}" for i in range(AD + 1)) + ";")
     out.append("    uint32_t " + ", ".join(f"tx{t}_{i}" for t in (0, 1) for i in range(10)) + ";")
     out.append("    uint64_t tc0_0, tc1_0;")
+    out.append("    uint32_t tm0;")
     out.append("    asm volatile(")
     for ln in S.lines:
         out.append('        "' + ln + '\\n\\t"')
@@ -274,6 +279,7 @@ def emit_loop(abl=0):
     outs += [f'[A{i}] "=&v"(tA{i})' for i in range(AD + 1)]
     outs += [f'[x{t}_{i}] "=&v"(tx{t}_{i})' for t in (0, 1) for i in range(10)]
     outs += [f'[c{t}_0] "=&s"(tc{t}_0)' for t in (0, 1)]
+    outs += ['[m0s] "=&s"(tm0)']
     ins = [f'[b{ks}_{n}] "a"(bq[{ks}][{n}])' for ks in range(12) for n in range(4)]
     ins += [f'[al{m}] "v"(al[{m}])' for m in range(2)] + [f'[ah{m}] "v"(ah[{m}])' for m in range(2)]
     ins += ['[dvoff] "v"(dma_voff)', '[stvoff] "v"(st_voff)', '[cshift] "v"(code_shift)', '[inv] "s"(inv_step_s)',
@@ -281,7 +287,7 @@ def emit_loop(abl=0):
     ins += [f'[o{128 * j}] "s"({128 * j}u)' for j in range(1, PIECES)]
     out.append("        : " + ",\n          ".join(outs))
     out.append("        : " + ",\n          ".join(ins))
-    out.append('        : "vcc", "scc", "m0", "memory");')
+    out.append('        : "vcc", "scc", "memory");')
     out.append("}")
     # schedule statistics on stderr
     n_nop = sum(1 for ln in S.lines if ln.startswith("s_nop"))

@@ -1599,11 +1599,14 @@ static int ce_reserve(rr_ce* ce, int64_t tokens) {
     ce->h32 = nullptr; ce->hb = ce->qkv = ce->ctx = ce->inter = nullptr;
     ce->cap = 0;
     const size_t n = (size_t)rr_round_up(tokens, 4096);
+    // the fp32 precision touches h32 / hb only (ce_embed_ln writes both); its own activations are ce_reserve_f32's: no
+    // bf16 qkv / ctx / inter for it (5.4 KB per token, 0.7 GB at the 131 072-token call size)
+    const bool bf16_path = ce->cfg.precision != RR_CE_PRECISION_F32;
     hipError_t e = hipMalloc((void**)&ce->h32, n * CE_H * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&ce->hb, n * CE_H * 2);
-    if (e == hipSuccess) e = hipMalloc((void**)&ce->qkv, n * 3 * CE_H * 2);
-    if (e == hipSuccess) e = hipMalloc((void**)&ce->ctx, n * CE_H * 2);
-    if (e == hipSuccess) e = hipMalloc((void**)&ce->inter, n * CE_FFN * 2);
+    if (e == hipSuccess && bf16_path) e = hipMalloc((void**)&ce->qkv, n * 3 * CE_H * 2);
+    if (e == hipSuccess && bf16_path) e = hipMalloc((void**)&ce->ctx, n * CE_H * 2);
+    if (e == hipSuccess && bf16_path) e = hipMalloc((void**)&ce->inter, n * CE_FFN * 2);
     if (e != hipSuccess) { rr_set_error("rr_ce_forward: activation scratch for %lld tokens: %s", (long long)tokens, hipGetErrorString(e)); return RR_E_NOMEM; }
     ce->cap = (int64_t)n;
     return RR_OK;
@@ -1735,8 +1738,10 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
     RR_HIP_TRY(hipSetDevice(ce->device));
     int rc = ce_reserve(ce, n_tokens);
     if (rc) return rc;
-    rc = ce_reserve_seqs(ce, n_seqs);
-    if (rc) return rc;
+    if (ce->cfg.precision != RR_CE_PRECISION_F32) {      // (the CLS-tail buffers of the bf16 path's last layer)
+        rc = ce_reserve_seqs(ce, n_seqs);
+        if (rc) return rc;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int T = (int)n_tokens;
     rc = ce_set_attributes(ce->device);

@@ -889,6 +889,19 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
                 }
                 __syncthreads();
                 tau = rr_f2key(floor[Q]);
+                if (counters[0] > RR_SEL_LCAP) {
+                    // A hot shard (skewed / clustered corpus): the floor is the MINIMUM over the shards, far below this shard's
+                    // own pool-th best row, and more groups reach it than the list holds.  The rows of the corpus-wide top-pool
+                    // that live here are among this shard's OWN top-pool, so its own threshold is a valid (higher) cut as
+                    // well: search it, like a shard without a floor does, and keep whichever of the two is higher.
+                    __syncthreads();
+                    if (tid == 0) counters[0] = 0;
+                    __syncthreads();
+                    const uint32_t floor_open = open, floor_tau = tau;
+                    tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2, 2.05f * e, &open, floor_open);
+                    tau = rr_f2key(rr_key2f(tau) - 1.02f * e);
+                    if (floor_tau > tau) tau = floor_tau;
+                }
             } else {
                 tau = rr_sel_open_groups(group_key_at, ng, pool, cnt, phase, counters, list2, eps ? 2.05f * e : -1.f, &open, 0u);
                 if (!eps) open = tau;

@@ -189,13 +189,15 @@ class HybridSearcher:
                                                 C.c_void_p(dense.data_ptr()), self._stream()), "rr_dense_select_dev")
         return rows, dense
 
-    def dense_scan_slot(self, slot: int, q_dev, pool: int, kth: int = 0):
+    def dense_scan_slot(self, slot: int, q_dev, pool: int, kth: int = 0, bound_out=None):
         """Phase 1 of the pipelined K1 (rr_dense_scan_slot_dev) on the CURRENT stream: the scan of ``q_dev`` into scan slot
-        ``slot`` (0 / 1).  ``kth`` > 0 (row shards): also the per-query bound of dense_scan, returned as a float32 (B,)
-        tensor; ``kth`` = 0: returns True.  None when the call cannot be split (then use dense_pool)."""
+        ``slot`` (0 .. 2).  ``kth`` > 0 (row shards): also the per-query bound of dense_scan, returned as a float32 (B,)
+        tensor (``bound_out`` if given); ``kth`` = 0: returns True.  None when the call cannot be split (then use dense_pool)."""
         torch = _torch()
         B = q_dev.shape[0]
-        bound = torch.empty((B,), dtype=torch.float32, device=self.device) if kth > 0 else None
+        bound = None
+        if kth > 0:
+            bound = bound_out if bound_out is not None else torch.empty((B,), dtype=torch.float32, device=self.device)
         applied = C.c_int32(0)
         _lib.check(self.lib.rr_dense_scan_slot_dev(self.index.handle, int(slot), C.c_void_p(q_dev.data_ptr()), B, pool, int(kth),
                                                    C.c_void_p(bound.data_ptr()) if kth > 0 else None, C.byref(applied),

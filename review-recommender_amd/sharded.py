@@ -92,12 +92,14 @@ class PendingExchange:
         return self.out
 
 
-def exchange_start(buf, world: int, group=None) -> PendingExchange:
+def exchange_start(buf, world: int, group=None, out=None) -> PendingExchange:
     """Starts the path's one collective (all-gather of every rank's payload buffer) without waiting for it: what lets
-    batch i's exchange run under K1 of batch i + 1 (ShardedSearcher.submit / finish)."""
+    batch i's exchange run under K1 of batch i + 1 (ShardedSearcher.submit / finish).  ``out``: a caller-owned
+    (world, nbytes) uint8 buffer to gather into."""
     import torch
     import torch.distributed as dist
-    out = torch.empty((world, buf.numel()), dtype=torch.uint8, device=buf.device)
+    if out is None:
+        out = torch.empty((world, buf.numel()), dtype=torch.uint8, device=buf.device)
     if world == 1:
         out[0].copy_(buf)
         return PendingExchange(out)
@@ -147,6 +149,18 @@ def exchange_floor(bound, world: int, group=None):
     return bound
 
 
+def exchange_floor_start(bound, world: int, group=None):
+    """exchange_floor without waiting for it (RCCL): returns the work handle whose wait() orders the CURRENT stream behind
+    the all-reduce, or None when it has already happened (one rank, gloo)."""
+    import torch.distributed as dist
+    if world == 1:
+        return None
+    if dist.get_backend(group) == "nccl":
+        return dist.all_reduce(bound, op=dist.ReduceOp.MIN, group=group, async_op=True)
+    exchange_floor(bound, world, group)
+    return None
+
+
 def split_pairs(n_pairs: int, world: int, rank: int) -> Tuple[int, int]:
     """Even split of the flattened (query, candidate) pair list of the rerank step across ranks
     ("pairs B x 200 are split evenly across ranks after the merge"): the same rule as shard_bounds."""
@@ -194,6 +208,58 @@ class PendingBatch:
     pending: "PendingExchange"
     gate_fn: object = None
     rerank_fn: object = None
+    # the overlapped form (ShardedSearcher.enable_overlap): stage 0 = scanned (K1's scan on the scans' stream, the floor's
+    # all-reduce started), 1 = payload built and its all-gather started, 2 = finished
+    stage: int = 1
+    slot: int = -1
+    bound: object = None
+    floor_work: object = None
+    terms: object = None
+    bm25_mode: str = "forward"
+
+
+class _Overlap:
+    """Streams and ring buffers of the overlapped shard step: scans on a stream masked to the first ``scan_cus`` CUs, every
+    batch's tail (selection against the floor, K2, metadata gather, payload all-gather, merge + K3) on a stream masked to the
+    rest, three batches deep (include/rr_hip.h: scan slots)."""
+    SLOTS = 3
+
+    def __init__(self, searcher: HybridSearcher, scan_cus: int):
+        import torch
+        lib, dev = searcher.lib, searcher.device
+        total = torch.cuda.get_device_properties(dev).multi_processor_count
+        if not (0 < scan_cus < total) or scan_cus % 32 or (total - scan_cus) % 32:
+            # the dispatcher deals one-per-CU workgroups to the 32 shader engines in turn: a share that is not a multiple of
+            # 32 leaves engines with CUs that get two of them (measured: 240 CUs take twice the time of 224)
+            raise ValueError(f"scan_cus {scan_cus} must be a multiple of 32 inside (0, {total})")
+        self.scan_cus, self.handles = scan_cus, []
+        streams = []
+        for first, n in ((0, scan_cus), (scan_cus, total - scan_cus)):
+            h = C.c_void_p()
+            _lib.check(lib.rr_stream_create_cu_range(dev.index, first, n, C.byref(h)), "rr_stream_create_cu_range")
+            self.handles.append(h)
+            streams.append(torch.cuda.ExternalStream(h.value, device=dev))
+        self.scan_stream, self.tail_stream = streams
+        _lib.check(lib.rr_index_set_scan_cus(searcher.index.handle, scan_cus), "rr_index_set_scan_cus")
+        self.lib, self.index = lib, searcher.index
+        self.seq = 0
+        self.pending = None            # the ticket whose payload has not been built yet (stage 0)
+        self.unfinished = 0
+        self.rings = {}                # (B, pool_local, pool, k, world) -> per-slot buffers
+
+    def buffers(self, key, make):
+        if key not in self.rings:
+            self.rings[key] = [make() for _ in range(self.SLOTS)]
+        return self.rings[key]
+
+    def close(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.index.handle:
+            _lib.check(self.lib.rr_index_set_scan_cus(self.index.handle, 0), "rr_index_set_scan_cus")
+        for h in self.handles:
+            _lib.check(self.lib.rr_stream_destroy(h), "rr_stream_destroy")
+        self.handles = []
 
 
 class ShardedSearcher:
@@ -211,12 +277,42 @@ class ShardedSearcher:
         # row shards select against a corpus-wide floor (two-phase K1 + exchange_floor); RR_NO_SHARD_FLOOR=1: every shard
         # selects on its own threshold (one collective less, ~8x the rescoring at 8 shards)
         self.use_floor = os.environ.get("RR_NO_SHARD_FLOOR") is None
+        self._ov: Optional[_Overlap] = None
+
+    def enable_overlap(self, scan_cus: Optional[int] = None) -> bool:
+        """Runs every batch's tail beside the NEXT batch's scan ("keep K1 -> K2-gather -> allgather -> K3 on-stream
+        ... pipeline batches"): the scans get a stream masked to ``scan_cus`` CUs (a multiple of 32), the tails one masked to
+        the rest (rr_stream_create_cu_range), and submit / finish become a three-stage pipeline -- scan(i + 1) | payload(i) |
+        merge(i - 1).  Answers are bit for bit those of the straight path (tests/test_gpu_sharded.py).
+        OFF unless asked for: ``scan_cus`` given, or RR_TAIL_OVERLAP_CUS=n in the environment (RR_NO_TAIL_OVERLAP=1 wins).
+        Measured on MI355X (profiles/r04_overlap_ab.md): the selection kernels are sized for the whole chip and whatever
+        runs beside the scan slows it, so at 10M rows per GPU the split loses (1.98-2.34 vs 1.93 ms per batch) and at
+        1.25M rows per shard the three stages alone take 0.29 | 0.23 | 0.18 ms on 160 | 96 | 96 CUs against 0.43 ms for the
+        whole step on one stream.  Returns whether the overlap is on."""
+        if self._ov is not None:
+            return True
+        if os.environ.get("RR_NO_TAIL_OVERLAP") is not None:
+            return False
+        forced = os.environ.get("RR_TAIL_OVERLAP_CUS")
+        if scan_cus is None and forced:
+            scan_cus = int(forced)
+        if scan_cus is None:
+            return False
+        self._ov = _Overlap(self.s, scan_cus)
+        return True
+
+    def disable_overlap(self) -> None:
+        if self._ov is not None:
+            self._flush_overlap()
+            self._ov.close()
+            self._ov = None
 
     def local_scan(self, q_dev, pool_local: int):
         """Phase 1 of K1 on this rank: the scan and this shard's bound per query (None: the call cannot be split)."""
         # the shards' kth best rows together hold >= pool rows for any kth >= ceil(pool / world).  A shard is only sure of
         # ~8 kth rescored rows (kth opened 8-row M-tiles): with kth >= ceil(pool / 8) + 1 its own list of `pool` rows
         # fills without the exact fallback also at world >= 8 (ceil(150 / 8) = 19 M-tiles = 152 rows would just do)
+        self._flush_overlap()
         kth = max((pool_local + self.world - 1) // self.world, (pool_local + 7) // 8 + 1)
         return self.s.dense_scan(q_dev, pool_local, min(kth, pool_local))
 
@@ -225,6 +321,7 @@ class ShardedSearcher:
         this rank.  ``floor``: tests that play several shards in one process pass the minimum they formed themselves
         (after calling local_scan on every shard); ``False`` = plain K1."""
         import torch
+        self._flush_overlap()
         s = self.s
         B = q_dev.shape[0]
         lay = PayloadLayout(B, pool_local)
@@ -277,6 +374,7 @@ class ShardedSearcher:
         two_pass = gate_fn is not None or (rerank_fn is not None and rr_k > 0)
         if self.world == 1 and not self.force_payload:
             # nothing to exchange: K1 -> K2 -> K3 straight through, metadata read from the index
+            self._flush_overlap()
             rows, dense = s.dense_pool(q_dev, pool)
             bm = s.bm25_at(tl, rows, bm25_mode)
             gate = rerank = None
@@ -309,13 +407,117 @@ class ShardedSearcher:
         if self.world > 1:
             assert pool_local == pool, "each shard needs at least `pool` rows"
         tl = term_id_lists if term_id_lists is not None else [[] for _ in range(B)]
+        two_pass = gate_fn is not None or (rerank_fn is not None and rr_k > 0)
+        if self._ov is not None:
+            if not two_pass:
+                t = self._submit_overlapped(q_dev, tl, B, k, pool, pool_local, w, bm25_mode)
+                if t is not None:
+                    return t
+            self._flush_overlap()      # a batch the pipeline does not take (host columns, a call K1 cannot split): in order, behind it
         lay, buf = self.local_payload(q_dev, tl, pool_local, bm25_mode)
         pending = exchange_start(buf, self.world, self.group)
         return PendingBatch(B, k, pool, pool_local, rr_k, w, lay, buf, pending, gate_fn, rerank_fn)
 
+    # ------------------------------------------------------------------ the overlapped form
+    def _flush_overlap(self) -> None:
+        """Builds the payload of the ticket still at stage 0 (its scan is parked in a slot: a plain K1 call would void it)."""
+        ov = self._ov
+        if ov is not None and ov.pending is not None:
+            t, ov.pending = ov.pending, None
+            self._build_payload(t)
+
+    def _submit_overlapped(self, q_dev, tl, B, k, pool, pool_local, w, bm25_mode):
+        import torch
+        import torch.distributed as dist
+        ov, s = self._ov, self.s
+        if ov.unfinished > 2:
+            raise RuntimeError("the overlapped pipeline is three batches deep: finish() earlier tickets before submitting more")
+        slot = ov.seq % ov.SLOTS
+        with_floor = self.world > 1 and self.use_floor and dist.is_available() and dist.is_initialized()
+        kth = 0
+        if with_floor:       # (local_scan's rule)
+            kth = min(max((pool_local + self.world - 1) // self.world, (pool_local + 7) // 8 + 1), pool_local)
+        cur = torch.cuda.current_stream(s.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)                                   # (the caller's stream produced q_dev)
+        with torch.cuda.stream(ov.scan_stream):
+            ov.scan_stream.wait_event(ready)
+            bound_ring = ov.buffers(("bound", B), lambda: torch.empty((B,), dtype=torch.float32, device=s.device))
+            bound = s.dense_scan_slot(slot, q_dev, pool_local, kth, bound_out=bound_ring[slot])
+            if bound is None:
+                return None
+            work = exchange_floor_start(bound, self.world, self.group) if with_floor else None
+        ov.seq += 1
+        ov.unfinished += 1
+        lay = PayloadLayout(B, pool_local)
+        t = PendingBatch(B, k, pool, pool_local, 0, w, lay, None, None, stage=0, slot=slot,
+                         bound=bound if with_floor else None, floor_work=work, terms=tl, bm25_mode=bm25_mode)
+        prev, ov.pending = ov.pending, t
+        if prev is not None:
+            self._build_payload(prev)                       # batch i - 1's tail goes to its stream beside this scan
+        return t
+
+    def _build_payload(self, t: "PendingBatch") -> None:
+        """Stage 1 on the tails' stream: selection (against the exchanged floor), K2, metadata gather into the slot's payload
+        buffer, and the all-gather is started."""
+        import torch
+        ov, s = self._ov, self.s
+        B, pool_local, lay = t.B, t.pool_local, t.lay
+        ring = ov.buffers(("payload", lay.nbytes, self.world), lambda: (
+            torch.empty(lay.nbytes, dtype=torch.uint8, device=s.device),
+            torch.empty((self.world, lay.nbytes), dtype=torch.uint8, device=s.device)))
+        buf, gathered = ring[t.slot]
+        v = lay.views(buf)
+        with torch.cuda.stream(ov.tail_stream):
+            if t.floor_work is not None:
+                t.floor_work.wait()                         # (orders this stream behind the all-reduce, not the host)
+            s.dense_select_slot(t.slot, B, pool_local, floor=t.bound, out=(v["rows"], v["dense"]))
+            s.bm25_at(t.terms, v["rows"], t.bm25_mode, out=v["bm25"])
+            _lib.check(s.lib.rr_index_gather_meta_dev(
+                s.index.handle, C.c_void_p(v["rows"].data_ptr()), B * pool_local,
+                C.c_void_p(v["n"].data_ptr()), C.c_void_p(v["avg"].data_ptr()),
+                C.c_void_p(v["l1p"].data_ptr()), s._stream()), "rr_index_gather_meta_dev")
+            t.pending = exchange_start(buf, self.world, self.group, out=gathered)
+        t.buf, t.stage, t.terms = buf, 1, None
+
+    def _finish_overlapped(self, t: "PendingBatch"):
+        import torch
+        ov, s = self._ov, self.s
+        if t.stage == 0:
+            if ov.pending is t:
+                ov.pending = None
+            self._build_payload(t)
+        B, k, pool, pool_local, w, lay = t.B, t.k, t.pool, t.pool_local, t.w, t.lay
+        k_out = min(k, pool)
+        out_rows, cols, order = ov.buffers(("out", B, pool, k_out), lambda: (
+            torch.empty((B, pool), dtype=torch.int64, device=s.device),
+            torch.empty((B, 8, pool), dtype=torch.float64, device=s.device),
+            torch.empty((B, k_out), dtype=torch.int32, device=s.device)))[t.slot]
+        cur = torch.cuda.current_stream(s.device)
+        with torch.cuda.stream(ov.tail_stream):
+            gathered = t.pending.wait()
+            base = gathered.data_ptr()
+            ptr = lambda off: C.c_void_p(base + off)
+            params = HybridSearcher.make_params(w, k_out, pool, self.world * pool_local, 0,
+                                                cand_per_rank=pool_local, stride_bytes=lay.nbytes)
+            _lib.check(s.lib.rr_fuse_topk_dev(
+                s.index.handle, C.byref(params), B, ptr(lay.off_rows), ptr(lay.off_dense), ptr(lay.off_bm25),
+                ptr(lay.off_n), ptr(lay.off_avg), ptr(lay.off_l1p), None, None, None,
+                C.c_void_p(out_rows.data_ptr()), C.c_void_p(cols.data_ptr()), C.c_void_p(order.data_ptr()), s._stream()),
+                "rr_fuse_topk_dev")
+            done = torch.cuda.Event()
+            done.record(ov.tail_stream)
+        cur.wait_event(done)                                # the caller's stream may read the answer
+        t.stage = 2
+        ov.unfinished -= 1
+        # (the answer lives in the slot's ring buffers: valid until three more batches have been submitted)
+        return out_rows, cols, order
+
     def finish(self, t: "PendingBatch"):
         """Second half: the gathered payload is merged and fused (K3; with a gate / reranker: merge, host columns, K3 again)."""
         import torch
+        if t.slot >= 0:
+            return self._finish_overlapped(t)
         s = self.s
         B, k, pool, pool_local, rr_k, w, lay = t.B, t.k, t.pool, t.pool_local, t.rr_k, t.w, t.lay
         gate_fn, rerank_fn = t.gate_fn, t.rerank_fn

@@ -261,3 +261,50 @@ def test_pipelined_submit_finish_equals_the_straight_path_bitwise():
         assert np.array_equal(cols.cpu().numpy(), wc, equal_nan=True) and np.array_equal(order.cpu().numpy(), wo)
     with pytest.raises(ValueError):
         sh.s.copy_segments([(torch.empty(4), torch.empty(4, device="cuda"))])      # pageable host memory is refused
+
+
+@pytest.mark.parametrize("scan_cus", [160, 224])
+def test_overlapped_shard_pipeline_equals_the_straight_path_bitwise(scan_cus):
+    """ShardedSearcher.enable_overlap: scan(i + 1) on a stream masked to `scan_cus` CUs beside payload(i) and merge(i - 1) on a
+    stream masked to the rest, two tickets in flight behind the one being submitted -- every answer bit for bit the straight
+    path's; a batch the pipeline does not take (3 queries: K1 cannot be split) goes through in order; more than three
+    unfinished tickets are refused."""
+    n, vocab = 200_000, 3000
+    V = synth.unit_rows(n, 384, 71)
+    n_rev, stars = synth.metadata(n, 72)
+    ip, terms, tf, dl = synth.bm25_forward_csr(n, vocab, 30, 73)
+    corpus = BM25Corpus(ip, terms, tf, dl, vocab)
+    sh = ShardedSearcher(build(V, n_rev.astype(np.float64), stars, corpus, 0, n), n, 0, 1)
+    sh.force_payload = True
+    w = FusionWeights(w_dense=0.5, w_bm25=0.5, w_rerank=0.0, w_prior=0.0, w_best=0.0, gate_penalty=1.0)
+    df = np.bincount(terms, minlength=vocab)
+    sizes = (256, 200, 256, 3, 37, 256, 128)
+    Qs = [synth.unit_rows(b, 384, 80 + i) for i, b in enumerate(sizes)]
+    tls = [synth.query_terms(b, vocab, 90 + i, df) for i, b in enumerate(sizes)]
+    want = [[t.cpu().numpy() for t in sh.search_batch_dev(torch.from_numpy(Q).cuda(), tl, 100, w)] for Q, tl in zip(Qs, tls)]
+    assert not sh.enable_overlap()                        # off unless asked for
+    assert sh.enable_overlap(scan_cus) and sh.enable_overlap()
+    try:
+        pins = [torch.from_numpy(Q).pin_memory() for Q in Qs]
+        got, inflight = [], []
+        for i in range(len(Qs)):
+            inflight.append(sh.submit(pins[i], tls[i], 100, w))
+            while len(inflight) > 2:
+                got.append([t.cpu().numpy() for t in sh.finish(inflight.pop(0))])
+        while inflight:
+            got.append([t.cpu().numpy() for t in sh.finish(inflight.pop(0))])
+        for i, ((rows, cols, order), (wr, wc, wo)) in enumerate(zip(got, want)):
+            assert np.array_equal(rows, wr) and np.array_equal(cols, wc, equal_nan=True) and np.array_equal(order, wo), i
+        # search_batch_dev on the overlapped searcher = submit + finish at once
+        again = [t.cpu().numpy() for t in sh.search_batch_dev(pins[0], tls[0], 100, w)]
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(again, want[0]))
+        tickets = [sh.submit(pins[0], tls[0], 100, w) for _ in range(3)]
+        with pytest.raises(RuntimeError, match="three batches deep"):
+            sh.submit(pins[0], tls[0], 100, w)
+        for t in tickets:
+            sh.finish(t)
+    finally:
+        sh.disable_overlap()
+    # and off again: the straight path still answers the same
+    back = [t.cpu().numpy() for t in sh.search_batch_dev(torch.from_numpy(Qs[1]).cuda(), tls[1], 100, w)]
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(back, want[1]))

@@ -57,18 +57,22 @@ k_loop:
 
 @pytest.fixture(scope="module")
 def scan_assembly(tmp_path_factory):
+    """source -> device assembly, for the product build and (key "debug:...") for the ablation harness's build of the filter
+    scans (-DRR_DEBUG_HARNESS + the generated timing ablations of the hand-scheduled loop): tools/ launch those on the GPU."""
     out = tmp_path_factory.mktemp("asm")
-    srcs = ["rr_dense_flt.hip", "rr_dense_x3w.hip", "rr_dense_x3.hip"]
-    B.check_generated()
+    jobs = [("rr_dense_flt.hip", False), ("rr_dense_x3w.hip", False), ("rr_dense_x3.hip", False), ("rr_dense_flt.hip", True)]
+    B.check_generated(debug=True)
 
-    def one(src):
-        dst = out / (src + ".s")
-        cmd = [B.hipcc_path(), *B.FLAGS, "--cuda-device-only", "-S", str(B.CSRC / src), "-o", str(dst)]
+    def one(job):
+        src, debug = job
+        dst = out / (("dbg_" if debug else "") + src + ".s")
+        flags = B.FLAGS + (B.DEBUG_FLAGS if debug else [])
+        cmd = [B.hipcc_path(), *flags, "--cuda-device-only", "-S", str(B.CSRC / src), "-o", str(dst)]
         p = subprocess.run(cmd, capture_output=True, text=True)
         assert p.returncode == 0, p.stderr[-2000:]
         return dst.read_text()
-    with ThreadPoolExecutor(3) as ex:
-        return dict(zip(srcs, ex.map(one, srcs)))
+    with ThreadPoolExecutor(4) as ex:
+        return dict(zip([("debug:" if d else "") + s for s, d in jobs], ex.map(one, jobs)))
 
 
 def test_no_shipped_scan_touches_a_ring_register_before_its_counted_wait(scan_assembly):
@@ -81,3 +85,26 @@ def test_no_shipped_scan_touches_a_ring_register_before_its_counted_wait(scan_as
             assert total == 0, (name, shown[:3])
             checked += 1 if loads else 0
     assert checked >= 20          # every instantiation with register loads was walked
+    # the harness build holds the product's instantiations plus the ablated ones: all of them were walked
+    dbg = set(re.findall(r"^(_Z\d+rr_scan_(?:flt|flt16|fltq)I\w+):", scan_assembly["debug:rr_dense_flt.hip"], flags=re.M))
+    prod = set(re.findall(r"^(_Z\d+rr_scan_(?:flt|flt16|fltq)I\w+):", scan_assembly["rr_dense_flt.hip"], flags=re.M))
+    assert prod <= dbg and len(dbg) > len(prod)
+
+
+def test_every_variant_a_tool_names_is_a_case_of_the_harness_switch():
+    """tools/flt_ablate.py and tools/fltq_ablate.py pass their variant numbers to rr_debug_scan_flt: a number that is not a
+    case of its switch stops the tool with "unknown ablation"  -- and a case whose kernel breaks the ring
+    contract must not come back through a tool's default list."""
+    src = (B.CSRC / "rr_dense_flt.hip").read_text()
+    body = src[src.index('extern "C" int rr_debug_scan_flt('):]
+    body = body[:body.index("#endif  // RR_DEBUG_HARNESS")]
+    cases = {int(x) for x in re.findall(r"^\s*case (\d+):", body, flags=re.M)}
+    cases |= {3000 + int(x) for x in re.findall(r"RR_FLTQA_CASE\((\d+)\)", body.split("#undef RR_FLTQA_CASE")[0].split("#define RR_FLTQA_CASE")[1])}
+    assert {0, 64, 128, 3000, 3128} <= cases and not ({15, 31} & cases)
+    assert {3000 + int(x) for x in B.FLTQ_ABLATIONS.split(",")} <= cases
+    flt = (ROOT / "tools" / "flt_ablate.py").read_text()
+    names = {int(x) for x in re.findall(r"[{ ,](\d+): \"", flt[flt.index("names = {"):flt.index("only = ")])}
+    assert names and names <= cases, sorted(names - cases)
+    fq = (ROOT / "tools" / "fltq_ablate.py").read_text()
+    default = [int(x) for x in re.search(r"else \[([\d, ]+)\]", fq).group(1).split(",")]
+    assert default and set(default) <= cases, sorted(set(default) - cases)

@@ -10,13 +10,15 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 lib = _lib.load()
 mat = torch.randn((n, 384), device="cuda"); mat /= mat.norm(dim=1, keepdim=True)
 ix = ProductIndex(None, n_rows=n, dim=384, device_ptr=mat.data_ptr(), keepalive=mat)
-ix.dense_topk(np.random.default_rng(0).standard_normal((256 if any(int(x) == 600 for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else [])) else 128, 384)).astype(np.float32), 150)
+ix.dense_topk(np.random.default_rng(0).standard_normal((128, 384)).astype(np.float32), 150)
+# (every key must be a case of rr_debug_scan_flt's switch: tests/test_ring_register_contract.py checks it.  15 / 31 -- ring
+#  loads with nothing reading them -- broke the register-ring contract and are gone from the harness.)
 names = {0: "full kernel", 1: "no epilogue", 2: "no B-fragment reads", 4: "no MFMA", 8: "no lane swaps / conversions",
-         3: "no epilogue, no B reads", 7: "loads + swaps + conversions only", 15: "ring loads + maxima stores only",
-         16: "no M-tile maxima stores", 31: "ring loads only", 32: "maxima stores non-temporal",
+         3: "no epilogue, no B reads", 7: "loads + swaps + conversions only",
+         16: "no M-tile maxima stores", 32: "maxima stores non-temporal",
          64: "bf16 plane: full kernel", 128: "bf16 plane: full kernel, ring loads from cache",
          256: "bf16 plane: stamped", 320: "bf16 plane: stamped, ring loads from cache",
-         400: "stamped, cached, no B-fragment reads", 600: "rr_scan_fltq (256 queries) stamped"}
+         400: "stamped, cached, no B-fragment reads"}
 only = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else None
 for v in (only or [0, 0] + list(names)[1:] + [0]):
     ms = C.c_float()
