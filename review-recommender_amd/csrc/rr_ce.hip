@@ -1412,6 +1412,202 @@ __global__ __launch_bounds__(256) void ce_attention_f32(const float* __restrict_
     }
 }
 
+// The same attention on the bf16 matrix cores by operand splitting (what ce_gemm_x3 does for the four GEMMs): every fp32
+// operand -- K, V, Q and the probabilities P -- is x = hi + mid + lo in three bf16 terms (24 bits), a product keeps the six
+// term pairs down to 2^-16 of it, fp32 accumulation in v_mfma_f32_32x32x16_bf16: 12 MFMAs of 8 passes per 32 x 32 x 32 block
+// instead of 16 v_mfma_f32_32x32x2_f32 of 16 passes (2.7x the matrix rate), and two waves per SIMD so that one wave's softmax
+// (scale, max, exp2, the split of P: ~170 vector instructions per 32 x 32 tile) runs under the other's MFMAs.
+//   * workgroup = one (sequence, head), 8 waves; wave w owns query tiles w and w + 8 (32 queries each: sequences up to 512);
+//   * keys go through LDS in chunks of 256: K as three bf16 terms [term][key][32 dims] (rows padded to 40: the A-operand
+//     ds_read_b128 of 32 keys x 8 dims is conflict-free), V transposed as three terms [term][dim][256 key slots] (rows padded
+//     to 264); the online softmax state of a wave's two query tiles lives in registers across the chunks;
+//   * S^T = K Q^T: A = K terms from LDS, B = Q terms (split in registers once per query tile and chunk); C layout as in
+//     ce_attention_f32: a lane holds one query's scores against 16 keys, register 4 g + i = key 8 g + 4 h + i (h = l >> 5);
+//   * O^T += V^T P^T: the B operand of k-step s wants, in lane (query, h), the probabilities of 8 keys -- registers 8 s .. 8 s
+//     + 7 AS THEY SIT, i.e. keys 16 s + 8 a + 4 h + i (a = 0, 1); the product sums over keys, so any order does as long as V^T
+//     uses the same one: key 16 s + 8 a + 4 h + i of a 32-key tile is stored at slot 16 s + 8 h + 4 a + i (bits 2 and 3 of
+//     the key swapped), and the A operand of lane (dim, h) is one 16-byte read.  No lane movement, no LDS round trip for P.
+// Scores, maxima, exp2 and sums stay fp32 vector arithmetic, as in ce_attention_f32: same 1e-5 bars (tests/test_gpu_k5.py).
+// RR_CE_F32_ATT_MFMA32=1 keeps ce_attention_f32 (A/B).
+#define CE_X3A_KC 256                                          // keys per LDS chunk
+#define CE_X3A_KLD 40                                          // bf16 per K row (32 + 8 pad)
+#define CE_X3A_VLD (CE_X3A_KC + 8)                             // bf16 per V^T row
+#define CE_X3A_LDS ((3 * CE_X3A_KC * CE_X3A_KLD + 3 * CE_HD * CE_X3A_VLD) * 2)
+struct ce_bf16x3 { __bf16 hi, mid, lo; };
+__device__ __forceinline__ ce_bf16x3 ce_split3(float x) {
+    ce_bf16x3 r;
+    r.hi = (__bf16)x;
+    const float r1 = x - (float)r.hi;
+    r.mid = (__bf16)r1;
+    r.lo = (__bf16)(r1 - (float)r.mid);
+    return r;
+}
+__global__ __launch_bounds__(512, 2) void ce_attention_x3(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
+                                                          float* __restrict__ ctx, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short x3a_lds[];
+    unsigned short* Kt = x3a_lds;                                          // [3][KC][KLD]
+    unsigned short* Vt = x3a_lds + 3 * CE_X3A_KC * CE_X3A_KLD;             // [3][32][VLD]
+    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    const int c = lane & 31, h = lane >> 5;
+    const float scale2 = scale * 1.4426950408889634f;        // the softmax in base 2
+    constexpr int NT = 2;                                     // query tiles per wave: w and w + 8
+    f32x16r o[NT];
+    float mx[NT], l[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        mx[t] = -INFINITY;
+        l[t] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    }
+    for (int k0 = 0; k0 < S; k0 += CE_X3A_KC) {
+        const int kn = S - k0 < CE_X3A_KC ? S - k0 : CE_X3A_KC;           // keys of this chunk
+        const int knp = (kn + 31) & ~31;
+        __syncthreads();                                      // the previous chunk has been read
+        // ---- K: thread -> (key, 4 dims): three 8-byte stores
+        for (int i = tid; i < knp * 8; i += 512) {
+            const int j = i >> 3, c4 = i & 7;
+            f32x4 k4 = {0.f, 0.f, 0.f, 0.f};
+            if (j < kn) k4 = *reinterpret_cast<const f32x4*>(qkv + (int64_t)(t0 + k0 + j) * (3 * CE_H) + CE_H + head * CE_HD + 4 * c4);
+            __bf16 t3[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const ce_bf16x3 x3 = ce_split3(k4[e]);
+                t3[0][e] = x3.hi; t3[1][e] = x3.mid; t3[2][e] = x3.lo;
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<bf16x4*>(Kt + (t * CE_X3A_KC + j) * CE_X3A_KLD + 4 * c4) = bf16x4{t3[t][0], t3[t][1], t3[t][2], t3[t][3]};
+            }
+        }
+        // ---- V^T: thread -> (key pair 2 m, 2 m + 1; 4 dims): per dim and term one 4-byte store at the pair's slot
+        for (int i = tid; i < (knp >> 1) * 8; i += 512) {
+            const int m = i >> 3, c4 = i & 7;
+            const int j = 2 * m;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (j < kn) va = *reinterpret_cast<const f32x4*>(qkv + (int64_t)(t0 + k0 + j) * (3 * CE_H) + 2 * CE_H + head * CE_HD + 4 * c4);
+            if (j + 1 < kn) vb = *reinterpret_cast<const f32x4*>(qkv + (int64_t)(t0 + k0 + j + 1) * (3 * CE_H) + 2 * CE_H + head * CE_HD + 4 * c4);
+            // slot of key j inside its 32-key tile: bits 2 and 3 swapped
+            const int in = j & 31;
+            const int slot = (j & ~31) + (in & 0x13) + ((in & 4) << 1) + ((in & 8) >> 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const ce_bf16x3 xa = ce_split3(va[e]), xb = ce_split3(vb[e]);
+                const __bf16 a3[3] = {xa.hi, xa.mid, xa.lo}, b3[3] = {xb.hi, xb.mid, xb.lo};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<bf16x2v*>(Vt + (t * CE_HD + 4 * c4 + e) * CE_X3A_VLD + slot) = bf16x2v{a3[t], b3[t]};
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int q0 = 32 * (wave + 8 * t);
+            if (q0 >= S) continue;                            // (wave-uniform)
+            int qrow = q0 + c;
+            qrow = qrow < S ? qrow : S - 1;                   // (lanes past the sequence: a valid row, never stored)
+            // ---- Q terms of this tile: lane (query c, h), k-step s: dims 16 s + 8 h .. + 7
+            bf16x8 qb[3][2];
+            {
+                const float* qp = qkv + (int64_t)(t0 + qrow) * (3 * CE_H) + head * CE_HD + 8 * h;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f32x4 q0v = *reinterpret_cast<const f32x4*>(qp + 16 * ks), q1v = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const ce_bf16x3 x0 = ce_split3(q0v[e]), x1 = ce_split3(q1v[e]);
+                        qb[0][ks][e] = x0.hi; qb[1][ks][e] = x0.mid; qb[2][ks][e] = x0.lo;
+                        qb[0][ks][4 + e] = x1.hi; qb[1][ks][4 + e] = x1.mid; qb[2][ks][4 + e] = x1.lo;
+                    }
+                }
+            }
+            for (int j0 = 0; j0 < knp; j0 += 32) {
+                // ---- S^T = K Q^T (smallest terms first)
+                bf16x8 ka[3][2];
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        ka[tt][ks] = *reinterpret_cast<const bf16x8*>(Kt + (tt * CE_X3A_KC + j0 + c) * CE_X3A_KLD + 16 * ks + 8 * h);
+                f32x16r sT;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sT[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[2][ks], qb[0][ks], sT, 0, 0, 0);
+                    sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0][ks], qb[2][ks], sT, 0, 0, 0);
+                    sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[1][ks], qb[1][ks], sT, 0, 0, 0);
+                    sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[1][ks], qb[0][ks], sT, 0, 0, 0);
+                    sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0][ks], qb[1][ks], sT, 0, 0, 0);
+                    sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[0][ks], qb[0][ks], sT, 0, 0, 0);
+                }
+                float cm = -INFINITY;
+                if (k0 + j0 + 32 > S) {                       // only the sequence's last tile holds padding keys
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = k0 + j0 + 8 * (e >> 2) + 4 * h + (e & 3);
+                        sT[e] = key < S ? sT[e] * scale2 : -INFINITY;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sT[e] *= scale2;
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cm = fmaxf(cm, sT[e]);
+                cm = fmaxf(cm, __shfl_xor(cm, 32, 64));       // the query's other 16 keys of this tile
+                if (cm > mx[t]) {                             // (per lane: a query's two lanes decide alike)
+                    const float r = __builtin_amdgcn_exp2f(mx[t] - cm);
+                    l[t] *= r;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[t][e] *= r;
+                    mx[t] = cm;
+                }
+                // ---- probabilities, split as they sit: registers 8 s .. 8 s + 7 = the B operand of k-step s
+                bf16x8 pb[3][2];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(sT[e] - mx[t]);      // masked keys: exp2(-inf) = 0
+                    l[t] += pe;
+                    const ce_bf16x3 p3 = ce_split3(pe);
+                    pb[0][e >> 3][e & 7] = p3.hi; pb[1][e >> 3][e & 7] = p3.mid; pb[2][e >> 3][e & 7] = p3.lo;
+                }
+                // ---- O^T += V^T P^T: A = V^T terms, lane (dim c, h), k-step s: slots 16 s + 8 h .. + 7 of this tile
+                bf16x8 va[3][2];
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        va[tt][ks] = *reinterpret_cast<const bf16x8*>(Vt + (tt * CE_HD + c) * CE_X3A_VLD + j0 + 16 * ks + 8 * h);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[2][ks], pb[0][ks], o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0][ks], pb[2][ks], o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1][ks], pb[1][ks], o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1][ks], pb[0][ks], o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0][ks], pb[1][ks], o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0][ks], pb[0][ks], o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int q0 = 32 * (wave + 8 * t);
+        const float lt = l[t] + __shfl_xor(l[t], 32, 64);
+        if (q0 + c < S) {
+            const float inv = 1.0f / lt;
+            float* op = ctx + (int64_t)(t0 + q0 + c) * CE_H + head * CE_HD + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)                       // register 4 g + i = dim 8 g + 4 h + i: 16 contiguous bytes per g
+                *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv};
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 struct rr_ce_layer {
     unsigned short *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;      // bf16 [N][K]
@@ -1666,6 +1862,7 @@ static int ce_set_attributes(int device) {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
 #endif
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * (CE_F32_KLD + CE_HD) * 4));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_x3, hipFuncAttributeMaxDynamicSharedMemorySize, CE_X3A_LDS));
     done[device] = true;
     return RR_OK;
 }
@@ -1701,8 +1898,13 @@ static int ce_forward_f32(rr_ce* ce, const int32_t* d_token_ids, const int32_t* 
         const rr_ce_layer& L = ce->layers[l];
         if (f32_x3) hipLaunchKernelGGL((ce_gemm_x3<false>), dim3(3 * CE_H / 128, mt), dim3(256), 0, st, ce->h32, L.wqkv32, L.bqkv, T, 3 * CE_H, CE_H, ce->qkv32);
         else hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(3 * CE_H / 128, mt), dim3(256), 0, st, ce->h32, L.wqkv32, L.bqkv, T, 3 * CE_H, CE_H, ce->qkv32);
-        hipLaunchKernelGGL(ce_attention_f32, dim3((unsigned)n_seqs, CE_HEADS), dim3(256), att_lds, st, ce->qkv32, d_cu_seqlens, ce->y32,
-                           0.17677669529663687f /* 1 / sqrt(32) */);
+        static const bool att_mfma32 = getenv("RR_CE_F32_ATT_MFMA32") != nullptr;      // (A/B: the fp32-input matrix instruction)
+        if (att_mfma32)
+            hipLaunchKernelGGL(ce_attention_f32, dim3((unsigned)n_seqs, CE_HEADS), dim3(256), att_lds, st, ce->qkv32, d_cu_seqlens, ce->y32,
+                               0.17677669529663687f /* 1 / sqrt(32) */);
+        else
+            hipLaunchKernelGGL(ce_attention_x3, dim3((unsigned)n_seqs, CE_HEADS), dim3(512), CE_X3A_LDS, st, ce->qkv32, d_cu_seqlens, ce->y32,
+                               0.17677669529663687f /* 1 / sqrt(32) */);
         // (y32 holds the context; the projection's output goes to the first T x 384 floats of inter32)
         if (f32_x3) hipLaunchKernelGGL((ce_gemm_x3<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->y32, L.wo32, L.bo, T, CE_H, CE_H, ce->inter32);
         else hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->y32, L.wo32, L.bo, T, CE_H, CE_H, ce->inter32);
