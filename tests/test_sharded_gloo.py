@@ -206,3 +206,57 @@ def test_started_exchanges_complete_in_order_and_match_the_blocking_form():
             g = ret[r][i]
             assert g.shape == (world, 48)
             assert np.all(g[0] == 10 * i) and np.all(g[1] == 10 * i + 1)
+
+
+def _overlap_flow_worker(rank, world, port, ret):
+    from review_recommender_amd.sharded import exchange_floor_start, exchange_start
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the collectives of ShardedSearcher.enable_overlap's three stages, in the order its submit / finish issue them:
+        #   submit(i):  floor all-reduce of batch i started (behind its scan), then payload all-gather of batch i - 1 started
+        #               into that slot's OWN gathered buffer (ring of three);
+        #   finish(i - 2): waits for batch i - 2's all-gather.
+        n = 5
+        rings = [torch.zeros((world, 32), dtype=torch.uint8) for _ in range(3)]
+        bounds = [torch.tensor([0.5 + 0.1 * i - 0.05 * rank, float("-inf") if (rank == 1 and i == 2) else 0.1 * i],
+                               dtype=torch.float32) for i in range(n)]
+        floors, pend, got = {}, {}, {}
+        for i in range(n + 2):
+            if i < n:
+                work = exchange_floor_start(bounds[i], world)          # gloo: done in place, nothing to wait for
+                assert work is None
+                floors[i] = bounds[i].numpy().copy()
+            if 0 <= i - 1 < n:
+                buf = torch.full((32,), 16 * (i - 1) + rank, dtype=torch.uint8)
+                pend[i - 1] = exchange_start(buf, world, out=rings[(i - 1) % 3])
+                assert pend[i - 1].out is rings[(i - 1) % 3]
+            if 0 <= i - 2 < n:
+                got[i - 2] = pend.pop(i - 2).wait().numpy().copy()   # (copied before the slot's buffer is gathered into again)
+        ret[rank] = (floors, got)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_pipeline_collectives_floor_started_then_gather_into_ring_buffers():
+    """The N > 1 side of ShardedSearcher.enable_overlap on CPU (its kernels need a GPU: tests/test_gpu_sharded.py): the
+    floor's all-reduce in its started form, the payload all-gather into caller-owned ring buffers three slots deep, two
+    batches in flight behind the one being submitted -- every rank ends with every batch's minimum and blocks."""
+    world = 2
+    port = free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_overlap_flow_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        floors, got = ret[r]
+        for i in range(5):
+            want = np.array([0.5 + 0.1 * i - 0.05, -np.inf if i == 2 else 0.1 * i], dtype=np.float32)
+            assert np.array_equal(floors[i], want), (r, i)
+            assert np.all(got[i][0] == 16 * i) and np.all(got[i][1] == 16 * i + 1), (r, i)
+    assert exchange_floor_start_single_rank()
+
+
+def exchange_floor_start_single_rank():
+    from review_recommender_amd.sharded import exchange_floor_start
+    b = torch.tensor([0.25, 0.5])
+    return exchange_floor_start(b, 1) is None and b.tolist() == [0.25, 0.5]

@@ -47,12 +47,22 @@ def main():
     peak = 2500.0 if a.precision == "bf16" else 157.3
     if a.precision == "fp32":
         flops = model_flops                                   # the fp32 mode computes every token of every layer
+    # attention is NOT on the MFMA roof: head dim 32 means one v_exp_f32 (quarter rate) per 64 MACs of QK^T + 64 of PV, and the
+    # fp32 mode adds the three-term split of every probability: its share of the forward is vector-bound.  Stated here so
+    # the whole-forward MFMA fraction below is not read as the attention kernels' own roof.
+    att_flops = a.layers * (4.0 * 384 * lens * lens).sum()
+    exps = a.layers * 12 * (lens * lens).sum()
+    bounds = {"gemm_kernels": "mfma (bf16 matrix cores%s)" % ("" if a.precision == "bf16" else ": six bf16 term products per fp32 product"),
+              "attention_kernels": {"bound": "vector (exp): one v_exp_f32 per score, 16 lanes per cycle and SIMD",
+                                    "share_of_model_flops": round(att_flops / model_flops, 4),
+                                    "exp_floor_ms_at_2.1GHz": round(exps / (256 * 4 * 16 * 2.1e9) * 1e3, 3)}}
     print(json.dumps({"precision": a.precision, "pairs": a.pairs, "tokens": int(T), "layers": a.layers, "forward_ms": round(t * 1e3, 3),
                       "pairs_per_s": round(a.pairs / t, 1), "tokens_per_s": round(T / t, 1),
                       "model_tflop": round(model_flops / 1e12, 4), "executed_tflop": round(flops / 1e12, 4),
                       "achieved_tflops": round(flops / t / 1e12, 2),
                       "roofline": {"bound": "mfma", "achieved": round(flops / t / 1e12, 2), "peak": peak,
-                                   "unit": "TFLOP/s", "frac": round(flops / t / (peak * 1e12), 4)}}))
+                                   "unit": "TFLOP/s", "frac": round(flops / t / (peak * 1e12), 4)},
+                      "bounds_by_kernel_family": bounds}))
 
 
 if __name__ == "__main__":
