@@ -333,12 +333,18 @@ def main():
     # Every batch is still submitted AND finished inside the timed region (drain() in front of the closing fence).
     pipelined = ((world > 1 or args.force_payload) and args.rerank_k == 0 and one_stream and kernel_copies
                  and os.environ.get("RR_BENCH_NO_PIPELINE") is None)
-    # RR_TAIL_OVERLAP_CUS=n (A/B; off by default: measured slower, profiles/r04_overlap_ab.md): submit / finish become a
-    # three-stage pipeline on two CU-masked streams -- scan(i + 1) on n CUs | selection + K2 + payload all-gather(i) | merge +
-    # K3(i - 1) on the rest -- and two batches stay in flight behind the one being submitted.
+    # Row shards (world > 1; RR_TAIL_OVERLAP_CUS=n forces it with one rank, RR_NO_TAIL_OVERLAP=1 turns it off): submit / finish
+    # are a three-stage pipeline on two CU-masked streams -- scan(i + 1) | selection + K2 + payload all-gather(i) | merge +
+    # K3(i - 1) -- and two batches stay in flight behind the one being submitted (profiles/r04_overlap_ab.md: a rank's step of
+    # eight shards 0.433 -> 0.350 ms on the one-GPU proxy; one GPU at 10M rows: no gain, hence off there).
     overlap = pipelined and sharded.enable_overlap()
     depth = 2 if overlap else 1
     inflight = []
+    if overlap:
+        # the masked streams are ordinary (blocking) HIP streams: every command on the NULL stream -- torch's default stream --
+        # would wait for both of them and hold both back.  The caller's side of the loop (answer copies, events) therefore
+        # runs on a non-blocking stream of its own.
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 
     def drain(keep=0):
         while len(inflight) > keep:

@@ -355,7 +355,10 @@ int rr_dense_select_slot_dev(rr_index* ix, int32_t slot, int32_t n_queries, int3
 int rr_dense_select_part_dev(rr_index* ix, int32_t slot, int32_t parts, int32_t n_queries, int32_t top_k, const float* d_floor,
                              int64_t* d_out_rows, float* d_out_scores, void* stream);
 /* A hipStream_t (as void*) whose kernels run only on CUs [first_cu, first_cu + n_cus) of `device`, counted in the driver's
- * CU-mask order (bit i sits on XCD i % 8: a contiguous range takes the same share of every XCD).  Destroy with rr_stream_destroy. */
+ * CU-mask order (bit i sits on XCD i % 8: a contiguous range takes the same share of every XCD).  n_cus should be a multiple
+ * of 32 (the dispatcher deals workgroups to the 32 shader engines in turn).  It is an ordinary BLOCKING stream: commands on
+ * the NULL stream synchronise with it -- keep other work off the NULL stream while it is in use.  Destroy with
+ * rr_stream_destroy before the process ends. */
 int rr_stream_create_cu_range(int32_t device, int32_t first_cu, int32_t n_cus, void** out_stream);
 int rr_stream_destroy(void* stream);
 /* How many CUs the stream of this index's scans may use (0 or the device's CU count = all). */

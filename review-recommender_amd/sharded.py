@@ -284,11 +284,17 @@ class ShardedSearcher:
         ... pipeline batches"): the scans get a stream masked to ``scan_cus`` CUs (a multiple of 32), the tails one masked to
         the rest (rr_stream_create_cu_range), and submit / finish become a three-stage pipeline -- scan(i + 1) | payload(i) |
         merge(i - 1).  Answers are bit for bit those of the straight path (tests/test_gpu_sharded.py).
-        OFF unless asked for: ``scan_cus`` given, or RR_TAIL_OVERLAP_CUS=n in the environment (RR_NO_TAIL_OVERLAP=1 wins).
-        Measured on MI355X (profiles/r04_overlap_ab.md): the selection kernels are sized for the whole chip and whatever
-        runs beside the scan slows it, so at 10M rows per GPU the split loses (1.98-2.34 vs 1.93 ms per batch) and at
-        1.25M rows per shard the three stages alone take 0.29 | 0.23 | 0.18 ms on 160 | 96 | 96 CUs against 0.43 ms for the
-        whole step on one stream.  Returns whether the overlap is on."""
+        The masked streams are blocking HIP streams: a caller that enqueues its own commands on the NULL stream (torch's
+        default stream) makes every one of them a barrier across both -- run the calling loop on a stream of its own
+        (``torch.cuda.set_stream(torch.cuda.Stream())``, as bench.py does).
+        ``scan_cus`` None: ON for real row shards (world > 1) with the split the full-step proxy measured best on MI355X
+        (tools/shard_step_proxy.py, profiles/r04_overlap_ab.md: per rank-step without the collectives' wire) --
+            <= 1.5M rows per shard (8 GPUs at 10M): 128 | 128 CUs   0.433 -> 0.350 ms
+            <= 3M   rows           (4 GPUs)       : 160 |  96       0.663 -> 0.584 ms
+            <= 6M   rows           (2 GPUs)       : 192 |  64       1.131 -> 1.016 ms
+        and OFF for one rank / larger shards (10M rows on one GPU lose: the tail needs the CUs there and whatever runs beside
+        the scan slows it).  RR_TAIL_OVERLAP_CUS=n forces a split (also with one rank), RR_NO_TAIL_OVERLAP=1 turns it off.
+        Returns whether the overlap is on."""
         if self._ov is not None:
             return True
         if os.environ.get("RR_NO_TAIL_OVERLAP") is not None:
@@ -296,6 +302,9 @@ class ShardedSearcher:
         forced = os.environ.get("RR_TAIL_OVERLAP_CUS")
         if scan_cus is None and forced:
             scan_cus = int(forced)
+        if scan_cus is None and self.world > 1:
+            n = self.s.index.n_rows
+            scan_cus = 128 if n <= 1_500_000 else 160 if n <= 3_000_000 else 192 if n <= 6_000_000 else None
         if scan_cus is None:
             return False
         self._ov = _Overlap(self.s, scan_cus)

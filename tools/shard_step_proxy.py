@@ -121,6 +121,7 @@ def overlapped_rank_step():
         return t
     cus = 160 if OVERLAP == "1" else int(OVERLAP)
     assert s0.enable_overlap(cus)
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))       # (not the NULL stream: it synchronises with the masked streams)
     s0.world = world                                            # the merge sees eight blocks of POOL candidates
     inflight = []
 
@@ -171,10 +172,29 @@ def overlapped_rank_step():
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
+    if os.environ.get("PROXY_HOST_SPLIT"):
+        # where the host's time per step goes (wall-clock around each call; the GPU is not waited for inside them)
+        acc = {}
+        def timed(name, fn):
+            def w(*a_, **k_):
+                h0 = time.perf_counter()
+                r = fn(*a_, **k_)
+                acc[name] = acc.get(name, 0.0) + time.perf_counter() - h0
+                return r
+            return w
+        s0._build_payload = timed("build_payload", s0._build_payload)
+        s0._finish_overlapped = timed("finish", s0._finish_overlapped)
+        s0.s.dense_scan_slot = timed("  scan_slot", s0.s.dense_scan_slot)
+        s0.s.dense_select_slot = timed("  select_slot", s0.s.dense_select_slot)
+        s0.s.bm25_at = timed("  bm25_at", s0.s.bm25_at)
+        s0.s.copy_segments = timed("  copy_segments", s0.s.copy_segments)
+        S.exchange_start = timed("  exchange_start(fake)", S.exchange_start)
     t0 = time.perf_counter()
     for _ in range(reps):
         one()
     host = (time.perf_counter() - t0) / reps * 1e3
+    if os.environ.get("PROXY_HOST_SPLIT"):
+        print(json.dumps({"host_us_per_step": {k: round(v / reps * 1e6, 1) for k, v in acc.items()}, "total_us": round(host * 1e3, 1)}), flush=True)
     if prof is not None:
         prof.disable()
         import pstats
