@@ -308,3 +308,62 @@ def test_overlapped_shard_pipeline_equals_the_straight_path_bitwise(scan_cus):
     # and off again: the straight path still answers the same
     back = [t.cpu().numpy() for t in sh.search_batch_dev(torch.from_numpy(Qs[1]).cuda(), tls[1], 100, w)]
     assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(back, want[1]))
+
+
+def test_hot_shard_whose_groups_all_reach_the_floor_selects_on_its_own_threshold():
+    """the corpus-wide floor is the MINIMUM of the shards' bounds.  With unequal, clustered shards the emptiest one
+    sets it far below a hot shard's own pool-th best row: every selection group of the hot shard reaches it and the list of
+    opened groups (4096) overflows.  The hot shard must then search its own threshold (a valid, higher cut: its rows of the
+    corpus-wide top-pool are among its own top-pool) instead of flagging every query for the exact fallback; the merged
+    answer stays bit for bit the unsharded one."""
+    n_hot, n_cold, batch, pool = 2_400_000, 600_000, 16, 150
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    centres = torch.randn((20_000, 384), generator=g, device="cuda")
+    centres /= centres.norm(dim=1, keepdim=True)
+    mat = torch.empty((n_hot + n_cold, 384), device="cuda")
+    for s0 in range(0, n_hot, 600_000):                     # the hot shard: rows around the centres the queries come from
+        who = torch.randint(0, centres.shape[0], (600_000,), generator=g, device="cuda")
+        blk = centres[who] + 0.5 / 384 ** 0.5 * torch.randn((600_000, 384), generator=g, device="cuda")
+        mat[s0:s0 + 600_000] = blk / blk.norm(dim=1, keepdim=True)
+    cold = torch.randn((n_cold, 384), generator=g, device="cuda")
+    mat[n_hot:] = cold / cold.norm(dim=1, keepdim=True)     # the cold shard: nothing near the queries
+    q = centres[torch.randint(0, centres.shape[0], (batch,), generator=g, device="cuda")] \
+        + 0.3 / 384 ** 0.5 * torch.randn((batch, 384), generator=g, device="cuda")
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    n = n_hot + n_cold
+    ones = np.ones(n)
+
+    def searcher(lo, hi):
+        ix = ProductIndex(None, n_rows=hi - lo, dim=384, row_offset=lo, device_ptr=mat[lo:hi].data_ptr(), keepalive=mat)
+        ix.set_meta(ones[lo:hi], ones[lo:hi])
+        return HybridSearcher(ix, None)
+
+    whole = searcher(0, n)
+    want_rows, want_dense = [t.cpu().numpy() for t in whole.dense_pool(q, pool)]
+    # (ShardedSearcher cuts the rows evenly; the unequal cut is the point here: the two-phase K1 is driven directly, with
+    #  local_scan's kth for two shards)
+    shards = [searcher(0, n_hot), searcher(n_hot, n)]
+    kth = max((pool + 1) // 2, (pool + 7) // 8 + 1)
+    bounds = [sh.dense_scan(q, pool, kth) for sh in shards]
+    assert all(b is not None for b in bounds)
+    floor = torch.stack(bounds).min(dim=0).values
+    # the cold shard sets the floor, far below the hot shard's own bound
+    assert (bounds[1] < bounds[0] - 0.2).all() and torch.equal(floor, bounds[1])
+    # ... so far that most ROWS of the hot shard reach it: all of its ~4 900 selection groups (2.4M rows = 37 500 tiles in
+    # 256 runs of groups of 8 tiles) would be listed -- more than the 4 096 the list holds
+    assert int((mat[:n_hot] @ q[0] >= floor[0]).sum()) > n_hot // 2
+    got_rows, got_dense = [], []
+    for sh in shards:
+        rows, dense = sh.dense_select(q, pool, floor)
+        torch.cuda.synchronize()
+        tr = sh.index.select_trace()
+        assert tr[0] == 2, "the two-pass path served query 0 (no exact fallback)"
+        assert tr[1] <= 4096
+        got_rows.append(rows.cpu().numpy())
+        got_dense.append(dense.cpu().numpy())
+    for b in range(batch):                                  # the merge K3 does: (dense desc, row asc), first `pool`
+        r = np.concatenate([got_rows[0][b], got_rows[1][b]])
+        d = np.concatenate([got_dense[0][b], got_dense[1][b]])
+        keep = np.lexsort((r, -d.astype(np.float64)))[:pool]
+        assert np.array_equal(r[keep], want_rows[b]) and np.array_equal(d[keep], want_dense[b]), b
