@@ -341,6 +341,10 @@ int rr_dense_scan_slot_dev(rr_index* ix, int32_t slot, const float* d_queries, i
                            float* d_bound, int32_t* applied, void* stream);
 int rr_dense_select_slot_dev(rr_index* ix, int32_t slot, int32_t n_queries, int32_t top_k, const float* d_floor,
                              int64_t* d_out_rows, float* d_out_scores, void* stream);
+/* rr_dense_topk_dev in a given scan slot (rr_dense_topk_dev itself = slot 0): the whole K1 of a batch the pipeline cannot
+ * split (`applied` = 0), without disturbing the scans other batches have parked in the other slots. */
+int rr_dense_topk_slot_dev(rr_index* ix, int32_t slot, const float* d_queries, int32_t n_queries, int32_t top_k,
+                           int64_t* d_out_rows, float* d_out_scores, void* stream);
 /* The selection in its three steps, each possibly on a stream of its own (`parts` = any combination, launched in this order):
  *   RR_SELECT_LIST     per query the 8-row M-tiles whose scan bound reaches the threshold (one workgroup per query: latency-
  *                      bound, a few CUs do);

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "rr_dense_select_dev": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rr_dense_scan_slot_dev": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp, P(c_i32), c_vp]),
     "rr_dense_select_slot_dev": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rr_dense_topk_slot_dev": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "rr_dense_select_part_dev": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rr_stream_create_cu_range": (C.c_int, [c_i32, c_i32, c_i32, P(c_vp)]),
     "rr_stream_destroy": (C.c_int, [c_vp]),

@@ -1610,9 +1610,9 @@ extern "C" int rr_dense_select_dev(rr_index* ix, const float* d_queries, int32_t
     return rr_dense_select_slot_dev(ix, 0, n_queries, pool, d_floor, d_out_rows, d_out_scores, stream);
 }
 
-extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n_queries,
-                                 int32_t pool, int64_t* d_out_rows, float* d_out_scores,
-                                 void* stream) {
+extern "C" int rr_dense_topk_slot_dev(rr_index* ix, int32_t slot, const float* d_queries, int32_t n_queries,
+                                      int32_t pool, int64_t* d_out_rows, float* d_out_scores,
+                                      void* stream) {
     RR_REQUIRE(ix && d_queries && d_out_rows && d_out_scores, "rr_dense_topk_dev: NULL argument");
     RR_REQUIRE(n_queries >= 1 && n_queries <= RR_MAX_BATCH, "rr_dense_topk_dev: n_queries %d out of [1,%d]",
                n_queries, RR_MAX_BATCH);
@@ -1625,7 +1625,7 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
     std::lock_guard<std::mutex> lk(ix->mu);
     RR_HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;  // NULL = the device's default stream
-    int rc0 = rr_slot_activate(ix, 0);
+    int rc0 = rr_slot_activate(ix, slot);
     if (rc0) return rc0;
     rr_flt_drop_pending(ix);
     // (the queries may sit in pinned host memory: rr_pad_queries then reads them over PCIe, once -- no copy command)
@@ -1648,6 +1648,12 @@ extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n
     ix->flt_prep_fresh = false;
     if (rc) return rc;
     return rr_scratch_leave(ix, st);
+}
+
+extern "C" int rr_dense_topk_dev(rr_index* ix, const float* d_queries, int32_t n_queries,
+                                 int32_t pool, int64_t* d_out_rows, float* d_out_scores,
+                                 void* stream) {
+    return rr_dense_topk_slot_dev(ix, 0, d_queries, n_queries, pool, d_out_rows, d_out_scores, stream);
 }
 
 extern "C" int rr_dense_topk(rr_index* ix, const float* h_queries, int32_t n_queries, int32_t pool,

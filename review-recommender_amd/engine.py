@@ -145,10 +145,11 @@ class HybridSearcher:
             segs[i] = _lib.CopySeg(dst.data_ptr(), src.data_ptr(), row_bytes, rows, dp, sp)
         _lib.check(self.lib.rr_copy_segments_dev(segs, len(pairs), self.device.index, self._stream()), "rr_copy_segments_dev")
 
-    def dense_pool(self, q_dev, pool: int, out=None):
+    def dense_pool(self, q_dev, pool: int, out=None, slot: int = 0):
         """K1 on device tensors: (rows int64 (B,pool), scores float32 (B,pool)).  ``q_dev``: (B, dim) float32 on the
         device -- or in PINNED host memory (K1's first kernel then reads the queries over PCIe itself: no copy command).
-        ``out`` = (rows, scores) tensors to write into (e.g. views of a shard payload)."""
+        ``out`` = (rows, scores) tensors to write into (e.g. views of a shard payload).  ``slot``: the scan slot whose state
+        the call uses (rr_dense_topk_slot_dev; 0 unless other batches have scans parked)."""
         torch = _torch()
         B = q_dev.shape[0]
         if out is not None:
@@ -156,9 +157,9 @@ class HybridSearcher:
         else:
             rows = torch.empty((B, pool), dtype=torch.int64, device=self.device)
             dense = torch.empty((B, pool), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.rr_dense_topk_dev(self.index.handle, C.c_void_p(q_dev.data_ptr()), B, pool,
-                                              C.c_void_p(rows.data_ptr()), C.c_void_p(dense.data_ptr()),
-                                              self._stream()), "rr_dense_topk_dev")
+        _lib.check(self.lib.rr_dense_topk_slot_dev(self.index.handle, int(slot), C.c_void_p(q_dev.data_ptr()), B, pool,
+                                                   C.c_void_p(rows.data_ptr()), C.c_void_p(dense.data_ptr()),
+                                                   self._stream()), "rr_dense_topk_dev")
         return rows, dense
 
     def dense_scan(self, q_dev, pool: int, kth: int):

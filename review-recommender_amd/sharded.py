@@ -216,6 +216,7 @@ class PendingBatch:
     floor_work: object = None
     terms: object = None
     bm25_mode: str = "forward"
+    plain_q: object = None        # set when K1 could not be split on this rank: the queries of the whole K1 stage 1 then runs
 
 
 class _Overlap:
@@ -453,14 +454,23 @@ class ShardedSearcher:
             ov.scan_stream.wait_event(ready)
             bound_ring = ov.buffers(("bound", B), lambda: torch.empty((B,), dtype=torch.float32, device=s.device))
             bound = s.dense_scan_slot(slot, q_dev, pool_local, kth, bound_out=bound_ring[slot])
+            plain_q = None
             if bound is None:
-                return None
+                if not with_floor:
+                    return None                             # (no floor exchange to keep in step: the caller's plain path)
+                # Row shards: whether K1 can be split may depend on THIS rank's rows (no finite row-norm bound: NaN / inf rows;
+                # a shard a few rows short of the filter path).  The ranks' collectives must stay in the same order, so this
+                # rank stays in the pipeline: it contributes "no floor" (-inf) to the all-reduce, and its stage 1 runs the
+                # whole K1 in its slot instead of the selection.
+                bound = bound_ring[slot]
+                bound.fill_(float("-inf"))
+                plain_q = q_dev
             work = exchange_floor_start(bound, self.world, self.group) if with_floor else None
         ov.seq += 1
         ov.unfinished += 1
         lay = PayloadLayout(B, pool_local)
         t = PendingBatch(B, k, pool, pool_local, 0, w, lay, None, None, stage=0, slot=slot,
-                         bound=bound if with_floor else None, floor_work=work, terms=tl, bm25_mode=bm25_mode)
+                         bound=bound if with_floor else None, floor_work=work, terms=tl, bm25_mode=bm25_mode, plain_q=plain_q)
         prev, ov.pending = ov.pending, t
         if prev is not None:
             self._build_payload(prev)                       # batch i - 1's tail goes to its stream beside this scan
@@ -480,14 +490,17 @@ class ShardedSearcher:
         with torch.cuda.stream(ov.tail_stream):
             if t.floor_work is not None:
                 t.floor_work.wait()                         # (orders this stream behind the all-reduce, not the host)
-            s.dense_select_slot(t.slot, B, pool_local, floor=t.bound, out=(v["rows"], v["dense"]))
+            if t.plain_q is not None:
+                s.dense_pool(t.plain_q, pool_local, out=(v["rows"], v["dense"]), slot=t.slot)
+            else:
+                s.dense_select_slot(t.slot, B, pool_local, floor=t.bound, out=(v["rows"], v["dense"]))
             s.bm25_at(t.terms, v["rows"], t.bm25_mode, out=v["bm25"])
             _lib.check(s.lib.rr_index_gather_meta_dev(
                 s.index.handle, C.c_void_p(v["rows"].data_ptr()), B * pool_local,
                 C.c_void_p(v["n"].data_ptr()), C.c_void_p(v["avg"].data_ptr()),
                 C.c_void_p(v["l1p"].data_ptr()), s._stream()), "rr_index_gather_meta_dev")
             t.pending = exchange_start(buf, self.world, self.group, out=gathered)
-        t.buf, t.stage, t.terms = buf, 1, None
+        t.buf, t.stage, t.terms, t.plain_q = buf, 1, None, None
 
     def _finish_overlapped(self, t: "PendingBatch"):
         import torch

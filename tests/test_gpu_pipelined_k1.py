@@ -83,6 +83,27 @@ def test_scan_on_one_stream_selection_on_another_is_bitwise_the_straight_call(wo
                 _lib.check(lib.rr_stream_destroy(h))
 
 
+def test_whole_k1_in_a_slot_of_its_own_leaves_the_scans_parked_in_the_others(world):
+    """rr_dense_topk_slot_dev: a batch the pipeline cannot split (here 3 queries) runs its whole K1 in slot 2 while slots 0
+    and 1 hold parked scans -- both are still selectable afterwards, bit for bit."""
+    s, Q, want = world
+    assert s.dense_scan_slot(0, Q[0], POOL) is True and s.dense_scan_slot(1, Q[1], POOL) is True
+    small = Q[3][:3].contiguous()
+    rows3, dense3 = s.dense_pool(small, POOL, slot=2)
+    ref3 = s.dense_pool(Q[3], POOL, slot=2)                 # (also in slot 2: the full batch of 37 for the reference rows)
+    assert torch.equal(rows3, ref3[0][:3]) and torch.equal(dense3, ref3[1][:3])
+    for slot in (1, 0):
+        rows, dense = s.dense_select_slot(slot, Q[slot].shape[0], POOL)
+        assert torch.equal(rows, want[slot][0]) and torch.equal(dense, want[slot][1]), slot
+    # ... whereas the same call in slot 0 voids what was parked THERE (and only there)
+    assert s.dense_scan_slot(0, Q[0], POOL) is True and s.dense_scan_slot(1, Q[1], POOL) is True
+    s.dense_pool(small, POOL)
+    with pytest.raises(ValueError, match="no scan of these"):
+        s.dense_select_slot(0, 256, POOL)
+    rows, dense = s.dense_select_slot(1, 256, POOL)
+    assert torch.equal(rows, want[1][0])
+
+
 def test_a_selection_without_its_scan_is_refused_and_small_calls_are_declined(world):
     s, Q, _ = world
     with pytest.raises(ValueError, match="no scan of these"):
