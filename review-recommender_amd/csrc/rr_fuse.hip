@@ -28,6 +28,7 @@ struct rr_fuse_dev_params {
     double log1p_sat;     // np.log1p(max(trust_sat, 1)) computed on the host
     float w_dense32, w_bm2532, w_rerank32, w_best32;
     int64_t row_offset, n_rows;
+    int32_t key_cap, col_cap;   // LDS capacities of THIS launch: sort keys (power of two >= n_candidates and pool), pool columns
 };
 
 // numpy's pairwise float64 sum (np.add.reduce on a contiguous array).
@@ -149,8 +150,10 @@ __device__ void rr_bitonic_desc_pairs(uint64_t* keys, int n) {
     __syncthreads();
 }
 
-// LDS plan: 32 K sort keys + 6 K reduction scratch + four float64 columns (64 K) + six float32
-// columns (48 K) + 8 K slot map = 158 K of the CU's 160 K: one workgroup per CU, by design.
+// LDS plan: sort keys + 6 K reduction scratch + four float64 columns + six float32 columns + the slot map, each sized for
+// THIS launch's pool and candidate count (rr_fuse_lds_bytes): 20 KB at pool 150 / 150 candidates, 38 KB when eight ranks'
+// lists are merged -- four to six workgroups share a CU (the kernel is latency-bound: on the few CUs a masked stream gives
+// it, or with more queries than CUs, that is the difference between one round and several) -- up to 158 KB at pool 2048.
 __global__ __launch_bounds__(RR_FUSE_THREADS) void rr_fuse(
     rr_fuse_dev_params fp, const int64_t* __restrict__ g_rows, const float* __restrict__ g_dense,
     const float* __restrict__ g_bm25, const double* __restrict__ g_n, const double* __restrict__ g_avg,
@@ -166,20 +169,21 @@ __global__ __launch_bounds__(RR_FUSE_THREADS) void rr_fuse(
     const int k = fp.p.k;
 
     // carve-up
-    uint64_t* keys = reinterpret_cast<uint64_t*>(lds);                    // RR_FUSE_MAXCAND
-    double* red = reinterpret_cast<double*>(keys + RR_FUSE_MAXCAND);       // 3 * threads
-    double* c_n = red + 3 * RR_FUSE_THREADS;                               // pool each, float64
-    double* c_avg = c_n + RR_MAX_POOL;
-    double* c_l1p = c_avg + RR_MAX_POOL;
-    double* c_prior = c_l1p + RR_MAX_POOL;
-    float* c_dense = reinterpret_cast<float*>(c_prior + RR_MAX_POOL);     // pool each, float32
-    float* c_bm25 = c_dense + RR_MAX_POOL;
-    float* c_rr = c_bm25 + RR_MAX_POOL;
-    float* c_best = c_rr + RR_MAX_POOL;
-    float* c_trust = c_best + RR_MAX_POOL;
-    float* c_final = c_trust + RR_MAX_POOL;
-    int32_t* c_src = reinterpret_cast<int32_t*>(c_final + RR_MAX_POOL);    // candidate slot of pool pos
-    double* s_scalar = reinterpret_cast<double*>(c_src + RR_MAX_POOL);     // 4 scalars
+    const int KC = fp.key_cap, PC = fp.col_cap;                            // (rr_fuse_lds_bytes: the same two numbers)
+    uint64_t* keys = reinterpret_cast<uint64_t*>(lds);                    // KC
+    double* red = reinterpret_cast<double*>(keys + KC);                    // 3 * threads
+    double* c_n = red + 3 * RR_FUSE_THREADS;                               // PC each, float64 (the merge's slot map, KC int32, sits here first)
+    double* c_avg = c_n + PC;
+    double* c_l1p = c_avg + PC;
+    double* c_prior = c_l1p + PC;
+    float* c_dense = reinterpret_cast<float*>(c_prior + PC);              // PC each, float32
+    float* c_bm25 = c_dense + PC;
+    float* c_rr = c_bm25 + PC;
+    float* c_best = c_rr + PC;
+    float* c_trust = c_best + PC;
+    float* c_final = c_trust + PC;
+    int32_t* c_src = reinterpret_cast<int32_t*>(c_final + PC);             // candidate slot of pool pos
+    double* s_scalar = reinterpret_cast<double*>(c_src + PC);              // 4 scalars
 
     const rr_cand_addr at{q, ncand, fp.p.cand_per_rank, fp.p.cand_rank_stride_bytes};
 
@@ -389,10 +393,21 @@ __global__ void rr_gather_meta(const int64_t* __restrict__ rows, int64_t n, int6
 }
 
 // ------------------------------------------------------------------ host side
-static size_t rr_fuse_lds_bytes() {
-    return sizeof(uint64_t) * RR_FUSE_MAXCAND + sizeof(double) * 3 * RR_FUSE_THREADS +
-           sizeof(double) * 4 * RR_MAX_POOL + sizeof(float) * 6 * RR_MAX_POOL +
-           sizeof(int32_t) * RR_MAX_POOL + sizeof(double) * 4;
+// LDS capacities of a launch: keys = the power of two the merge / the final sort pad to; columns = pool rounded up to 64,
+// and at least KC / 8 doubles per float64 column area so that the merge's slot map (KC int32 in the four float64 columns'
+// space) fits: 4 columns x PC x 8 B >= KC x 4 B.
+static void rr_fuse_caps(const rr_fuse_params* p, int32_t* key_cap, int32_t* col_cap) {
+    int kc = 64;
+    while (kc < p->n_candidates || kc < p->pool) kc <<= 1;
+    int pc = (p->pool + 63) / 64 * 64;
+    if (pc * 8 < kc) pc = kc / 8;
+    *key_cap = kc;
+    *col_cap = pc;
+}
+static size_t rr_fuse_lds_bytes(int key_cap, int col_cap) {
+    return sizeof(uint64_t) * (size_t)key_cap + sizeof(double) * 3 * RR_FUSE_THREADS +
+           sizeof(double) * 4 * (size_t)col_cap + sizeof(float) * 6 * (size_t)col_cap +
+           sizeof(int32_t) * (size_t)col_cap + sizeof(double) * 4;
 }
 
 static int rr_fuse_check(const rr_index* ix, const rr_fuse_params* p, int32_t nq, const void* rows,
@@ -440,8 +455,18 @@ extern "C" int rr_fuse_topk_dev(rr_index* ix, const rr_fuse_params* p, int32_t n
     fp.w_best32 = (float)p->w_best;
     fp.row_offset = ix->row_offset;
     fp.n_rows = ix->n_rows;
-    const size_t lds = rr_fuse_lds_bytes();
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)rr_fuse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    rr_fuse_caps(p, &fp.key_cap, &fp.col_cap);
+    const size_t lds = rr_fuse_lds_bytes(fp.key_cap, fp.col_cap);
+    static std::mutex attr_mu;
+    static bool attr_done[64] = {false};
+    {   // (the opt-in to more than 64 KB of dynamic LDS is per device, once: the largest launch)
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (ix->device >= 0 && ix->device < 64 && !attr_done[ix->device]) {
+            RR_HIP_TRY(hipFuncSetAttribute((const void*)rr_fuse, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)rr_fuse_lds_bytes(RR_FUSE_MAXCAND, RR_MAX_POOL)));
+            attr_done[ix->device] = true;
+        }
+    }
     hipLaunchKernelGGL(rr_fuse, dim3(n_queries), dim3(RR_FUSE_THREADS), lds, st, fp, d_rows, d_dense,
                        d_bm25, d_n_reviews, d_avg_stars, d_log1p_n, d_rerank, d_best, d_gate,
                        ix->d_n_reviews, ix->d_avg_stars, ix->d_log1p_n, d_out_rows, d_out_cols,
