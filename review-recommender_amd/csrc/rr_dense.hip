@@ -34,6 +34,8 @@
 #define RR_SEL_GCAP 4096    // slow path: tiles kept in LDS
 #define RR_SEL_CCAP 12288   // candidate keys in LDS: the fast paths collect into the first half (6144) and sort in <= 8192
 #define RR_SEL_SORTCAP 8192 // largest power of two inside it: the generic path collects up to this many
+#define RR_SEL_RCAP 8192    // rr_select_rescored's key area for pools up to 512 (64 KB: two of its workgroups share a CU; rows are collected
+                            // into the first half); larger pools take RR_SEL_CCAP
 #define RR_SEL_LCAP 4096    // groups opened by the fast path
 
 // ------------------------------------------------------------------ scan
@@ -1006,13 +1008,14 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_mtiles(
     }
 }
 
+template <int RCAP>
 __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
     rr_scan_geom G, const uint32_t* __restrict__ mtiles, const int32_t* __restrict__ count,
     const uint32_t* __restrict__ tau_of, const float* __restrict__ sc, int pool, int64_t row_offset,
     int64_t* __restrict__ out_rows, float* __restrict__ out_scores, int32_t* __restrict__ fb,
     int32_t* __restrict__ dbg, int floor_mode) {
     __shared__ uint32_t counters[2];
-    __shared__ uint64_t cand[RR_SEL_CCAP];
+    __shared__ uint64_t cand[RCAP];
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
     if (fb[q]) return;
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
     const int n1 = count[q] << sh;
     // (row shards under a corpus-wide floor: the best `pool` of ALL rescored rows is the answer whether or not `pool` of them
     //  reach the cut -- one pass when they fit)
-    const bool all_rows = floor_mode && (uint32_t)n1 <= RR_SEL_CCAP / 2;
+    const bool all_rows = floor_mode && (uint32_t)n1 <= RCAP / 2;
     for (int i = tid; i < n1 && !all_rows; i += RR_SEL_THREADS) {
         const int64_t at = (int64_t)q * RR_X3_MCAP + (i >> sh);
         const int r = i & ((1 << sh) - 1);
@@ -1032,13 +1035,13 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
             const uint32_t key = rr_f2key(sc[(at << sh) + r]);
             if (key >= tau) {
                 const uint32_t slot = atomicAdd(&counters[0], 1u);
-                if (slot < RR_SEL_CCAP / 2) cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - row);
+                if (slot < RCAP / 2) cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - row);
             }
         }
     }
     __syncthreads();
     uint32_t n_cand = counters[0];
-    if (all_rows || (floor_mode && n_cand < (uint32_t)pool && (uint32_t)n1 <= RR_SEL_CCAP / 2)) {
+    if (all_rows || (floor_mode && n_cand < (uint32_t)pool && (uint32_t)n1 <= RCAP / 2)) {
         // Row shards with a corpus-wide floor: fewer M-tiles were opened than this shard's own top-pool needs, so fewer
         // than `pool` rows may reach its own cut.  Every row of the corpus-wide top-pool that lives here IS among the
         // rescored rows; the list is filled up with the best of the other rescored rows (exact scores, below the
@@ -1053,14 +1056,14 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
             if ((int64_t)row < G.n_rows) {
                 const uint32_t key = rr_f2key(sc[(at << sh) + r]);
                 const uint32_t slot = atomicAdd(&counters[0], 1u);
-                if (slot < RR_SEL_CCAP / 2) cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - row);
+                if (slot < RCAP / 2) cand[slot] = ((uint64_t)key << 32) | (uint64_t)(0xFFFFFFFFu - row);
             }
         }
         __syncthreads();
         n_cand = counters[0];
     }
     if (tid == 0) dbg[q * 16 + 3] = (int32_t)n_cand;
-    if (n_cand > RR_SEL_CCAP / 2 || n_cand < (uint32_t)pool) {    // massive ties at the cut
+    if (n_cand > RCAP / 2 || n_cand < (uint32_t)pool) {    // massive ties at the cut
         if (tid == 0) {
             fb[q] = 1;
             dbg[q * 16 + 0] = 0;
@@ -1068,8 +1071,8 @@ __global__ __launch_bounds__(RR_SEL_THREADS) void rr_select_rescored(
         return;
     }
     if (n_cand <= RR_SEL_THREADS) {
-        rr_rank_sort_desc(cand, (int)n_cand, cand + RR_SEL_CCAP / 2);
-        for (int i = tid; i < pool; i += RR_SEL_THREADS) cand[i] = cand[RR_SEL_CCAP / 2 + i];
+        rr_rank_sort_desc(cand, (int)n_cand, cand + RCAP / 2);
+        for (int i = tid; i < pool; i += RR_SEL_THREADS) cand[i] = cand[RCAP / 2 + i];
         __syncthreads();
     } else {
         int n_sort = 1;
@@ -1113,8 +1116,13 @@ void rr_launch_select_mtiles(rr_index* ix, const rr_scan_geom& G, int nq, int po
 void rr_launch_select_rescored(rr_index* ix, const rr_scan_geom& G, int nq, int pool, int64_t* d_rows,
                                float* d_scores, hipStream_t st, bool floor_mode) {
     const rr_x3_scratch s = rr_x3_scratch_of(ix);
-    hipLaunchKernelGGL(rr_select_rescored, dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, s.mtiles, s.count, s.tau,
-                       s.sc, pool, ix->row_offset, d_rows, d_scores, s.fb, ix->d_sel_trace, floor_mode ? 1 : 0);
+    // (pools up to 512 -- every BASELINE configuration -- fit the 64 KB key area: two workgroups per CU)
+    if (pool <= 512)
+        hipLaunchKernelGGL((rr_select_rescored<RR_SEL_RCAP>), dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, s.mtiles, s.count, s.tau,
+                           s.sc, pool, ix->row_offset, d_rows, d_scores, s.fb, ix->d_sel_trace, floor_mode ? 1 : 0);
+    else
+        hipLaunchKernelGGL((rr_select_rescored<RR_SEL_CCAP>), dim3(nq), dim3(RR_SEL_THREADS), 0, st, G, s.mtiles, s.count, s.tau,
+                           s.sc, pool, ix->row_offset, d_rows, d_scores, s.fb, ix->d_sel_trace, floor_mode ? 1 : 0);
 }
 
 // bound[Q] = (a lower bound of) the kth largest group maximum of the filter scores of query Q, minus 1.01 eps: at least
