@@ -26,7 +26,7 @@ DEBUG_LIB_PATH = PKG_DIR / "librr_hip_dbg.so"
 DEBUG_BUILD_ID = PKG_DIR / "librr_hip_dbg.so.buildid"
 DEBUG_FLAGS = ["-DRR_DEBUG_HARNESS"]
 SOURCES = ["rr_api.hip", "rr_dense.hip", "rr_dense_bf16.hip", "rr_dense_x3.hip", "rr_dense_x3w.hip",
-           "rr_dense_flt.hip", "rr_bm25.hip", "rr_fuse.hip", "rr_reviews.hip", "rr_ce.hip"]
+           "rr_dense_flt.hip", "rr_bm25.hip", "rr_fuse.hip", "rr_reviews.hip", "rr_ce.hip", "rr_ce_h2.hip"]
 # -ffp-contract=off: the BM25 and fusion kernels reproduce numpy's one-rounding-per-
 # operation arithmetic; fused multiply-adds are written out (__builtin_fmaf) where wanted.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]

@@ -26,10 +26,12 @@
 // GEMM tiles: 32x32x16 bf16 MFMA, K-step 64 through LDS rows padded to 144 B (conflict-free ds_read_b128),
 // next K tile prefetched global -> registers under the MFMAs of the current one.
 #include <cmath>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
 #include "rr_common.h"
+#include "rr_ce_h2.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -1442,8 +1444,13 @@ __device__ __forceinline__ ce_bf16x3 ce_split3(float x) {
     r.lo = (__bf16)(r1 - (float)r.mid);
     return r;
 }
+// H2OUT: the context leaves as an h2 image (rr_ce_h2.h; chunk = head * 4 + g, half h of the unit) for ce_gemm_h2.
+template <bool H2OUT>
 __global__ __launch_bounds__(512, 2) void ce_attention_x3(const float* __restrict__ qkv, const int32_t* __restrict__ cu,
-                                                          float* __restrict__ ctx, float scale) {
+                                                          float* __restrict__ ctx, float scale, u32x2* __restrict__ ctx2 = nullptr,
+                                                          int64_t os = 0, unsigned* __restrict__ flag = nullptr, int cls_only = 0) {
+    // cls_only (the last layer of a [CLS]-pooled output): only query 0 of the sequence is wanted -- one query tile, by wave 0,
+    // and its context row goes to row `seq` of a compact image (one row per sequence)
     extern __shared__ __attribute__((aligned(16))) unsigned short x3a_lds[];
     unsigned short* Kt = x3a_lds;                                          // [3][KC][KLD]
     unsigned short* Vt = x3a_lds + 3 * CE_X3A_KC * CE_X3A_KLD;             // [3][32][VLD]
@@ -1507,7 +1514,7 @@ __global__ __launch_bounds__(512, 2) void ce_attention_x3(const float* __restric
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int q0 = 32 * (wave + 8 * t);
-            if (q0 >= S) continue;                            // (wave-uniform)
+            if (q0 >= S || (cls_only && q0 != 0)) continue;   // (wave-uniform)
             int qrow = q0 + c;
             qrow = qrow < S ? qrow : S - 1;                   // (lanes past the sequence: a valid row, never stored)
             // ---- Q terms of this tile: lane (query c, h), k-step s: dims 16 s + 8 h .. + 7
@@ -1598,12 +1605,32 @@ __global__ __launch_bounds__(512, 2) void ce_attention_x3(const float* __restric
     for (int t = 0; t < NT; ++t) {
         const int q0 = 32 * (wave + 8 * t);
         const float lt = l[t] + __shfl_xor(l[t], 32, 64);
-        if (q0 + c < S) {
+        if (q0 + c < S && (!cls_only || q0 + c == 0)) {
             const float inv = 1.0f / lt;
-            float* op = ctx + (int64_t)(t0 + q0 + c) * CE_H + head * CE_HD + 4 * h;
+            if (H2OUT) {
+                bool bad = false;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)                       // register 4 g + i = dim 8 g + 4 h + i: 16 contiguous bytes per g
-                *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv};
+                for (int g = 0; g < 4; ++g) {
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    f16x4 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = o[t][4 * g + i] * inv;
+                        hi[i] = __builtin_fabsf(v) < 6.103515625e-05f ? (_Float16)0.f : (_Float16)v;      // (h2_split, rr_ce_h2.hip)
+                        lo[i] = (_Float16)((v - (float)hi[i]) * CE_H2_SCALE);
+                        bad |= !(__builtin_fabsf(v) <= 65504.f);
+                    }
+                    const int64_t u = (int64_t)(head * 4 + g) * os + (cls_only ? seq : t0 + q0 + c);
+                    ctx2[2 * u + h] = __builtin_bit_cast(u32x2, hi);
+                    ctx2[2 * ((int64_t)(CE_H / 8) * os + u) + h] = __builtin_bit_cast(u32x2, lo);
+                }
+                if (bad) atomicOr(flag, 1u);
+            } else {
+                float* op = ctx + (int64_t)(t0 + q0 + c) * CE_H + head * CE_HD + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)                       // register 4 g + i = dim 8 g + 4 h + i: 16 contiguous bytes per g
+                    *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv};
+            }
         }
     }
 }
@@ -1615,6 +1642,7 @@ struct rr_ce_layer {
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
     float *wqkv32 = nullptr, *wo32 = nullptr, *w1_32 = nullptr, *w2_32 = nullptr;     // RR_CE_PRECISION_F32: the Linear weights as given
+    void *wqkv_h2 = nullptr, *wo_h2 = nullptr, *w1_h2 = nullptr, *w2_h2 = nullptr;      // ... and as h2 images (rr_ce_h2.h)
 };
 
 struct rr_ce {
@@ -1635,6 +1663,12 @@ struct rr_ce {
     // RR_CE_PRECISION_F32: fp32 activations
     int64_t cap32 = 0;
     float *qkv32 = nullptr, *y32 = nullptr, *inter32 = nullptr;
+    int64_t cap32_seqs = 0;                    // ... and of the last layer's [CLS]-only tail: one row per sequence
+    float *h32c32 = nullptr, *y32c = nullptr;
+    void *hxc = nullptr, *ctxhc = nullptr, *interhc = nullptr;
+    void *hx = nullptr, *ctxh = nullptr;      // h2 images of the residual stream / the attention context (inter32 doubles as the FFN's)
+    unsigned* d_flag = nullptr;                // OR-ed with 1 by a producer that met a value outside fp16's range
+    bool wide_range = false;                   // rr_ce_set_wide_range: the bf16 three-term kernels (any fp32 range)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     std::mutex mu;
@@ -1685,12 +1719,15 @@ extern "C" int rr_ce_destroy(rr_ce* ce) {
             hipFree(L.bqkv); hipFree(L.bo); hipFree(L.b1); hipFree(L.b2);
             hipFree(L.ln1_g); hipFree(L.ln1_b); hipFree(L.ln2_g); hipFree(L.ln2_b);
             hipFree(L.wqkv32); hipFree(L.wo32); hipFree(L.w1_32); hipFree(L.w2_32);
+            hipFree(L.wqkv_h2); hipFree(L.wo_h2); hipFree(L.w1_h2); hipFree(L.w2_h2);
         }
     delete[] ce->layers;
     hipFree(ce->wp); hipFree(ce->bp); hipFree(ce->wc); hipFree(ce->bc); hipFree(ce->gelu_tab);
     hipFree(ce->h32); hipFree(ce->hb); hipFree(ce->qkv); hipFree(ce->ctx); hipFree(ce->inter);
     hipFree(ce->h32c); hipFree(ce->hbc); hipFree(ce->ctxc); hipFree(ce->interc);
     hipFree(ce->qkv32); hipFree(ce->y32); hipFree(ce->inter32);
+    hipFree(ce->hx); hipFree(ce->ctxh); hipFree(ce->d_flag);
+    hipFree(ce->h32c32); hipFree(ce->y32c); hipFree(ce->hxc); hipFree(ce->ctxhc); hipFree(ce->interhc);
     if (ce->ev0) hipEventDestroy(ce->ev0);
     if (ce->ev1) hipEventDestroy(ce->ev1);
     delete ce;
@@ -1770,6 +1807,16 @@ extern "C" int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float
             f32(&L.wo32, p[6], H * H);
             f32(&L.w1_32, p[10], F * H);
             f32(&L.w2_32, p[12], H * F);
+            // the same four matrices as h2 images (two fp16 planes, as large as the fp32 matrix): ce_gemm_h2's A operand
+            auto h2 = [&](void** d, const float* src32, size_t n, size_t k) {
+                if (rc) return;
+                if (hipMalloc(d, n * k * 4) != hipSuccess) { rc = RR_E_NOMEM; return; }
+                ce_h2_pack(src32, (int)n, (int)k, *d, (int64_t)n, nullptr);
+            };
+            h2(&L.wqkv_h2, L.wqkv32, 3 * H, H);
+            h2(&L.wo_h2, L.wo32, H, H);
+            h2(&L.w1_h2, L.w1_32, F, H);
+            h2(&L.w2_h2, L.w2_32, H, F);
         }
     }
     if (!rc && cfg->n_labels > 0) {
@@ -1783,6 +1830,8 @@ extern "C" int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float
         f32(&ce->gelu_tab, tab.data(), tab.size());
     }
     if (!rc && (hipEventCreate(&ce->ev0) != hipSuccess || hipEventCreate(&ce->ev1) != hipSuccess)) rc = RR_E_HIP;
+    if (!rc && (hipMalloc((void**)&ce->d_flag, 4) != hipSuccess || hipMemset(ce->d_flag, 0, 4) != hipSuccess)) rc = RR_E_NOMEM;
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = RR_E_HIP;      // (the weight images are packed)
     if (rc) { rr_ce_destroy(ce); return rc; }
     *out = ce;
     return RR_OK;
@@ -1862,7 +1911,9 @@ static int ce_set_attributes(int device) {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_ffn_fused<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_FFN_LDS));
 #endif
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_f32, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * (CE_F32_KLD + CE_HD) * 4));
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_x3, hipFuncAttributeMaxDynamicSharedMemorySize, CE_X3A_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_X3A_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CE_X3A_LDS));
+    if (int rc = ce_h2_set_attributes()) return rc;
     done[device] = true;
     return RR_OK;
 }
@@ -1870,13 +1921,20 @@ static int ce_set_attributes(int device) {
 static int ce_reserve_f32(rr_ce* ce, int64_t tokens) {
     if (tokens <= ce->cap32) return RR_OK;
     RR_HIP_TRY(hipDeviceSynchronize());
-    hipFree(ce->qkv32); hipFree(ce->y32); hipFree(ce->inter32);
+    hipFree(ce->qkv32); hipFree(ce->y32); hipFree(ce->inter32); hipFree(ce->hx); hipFree(ce->ctxh);
     ce->qkv32 = ce->y32 = ce->inter32 = nullptr;
+    ce->hx = ce->ctxh = nullptr;
     ce->cap32 = 0;
-    const size_t n = (size_t)rr_round_up(tokens, 4096);
+    const size_t n = (size_t)rr_round_up(tokens, 4096);      // (= the row stride of the h2 images: a multiple of 256)
     hipError_t e = hipMalloc((void**)&ce->qkv32, n * 3 * CE_H * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&ce->y32, n * CE_H * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&ce->inter32, n * CE_FFN * 4);
+    if (e == hipSuccess) e = hipMalloc(&ce->hx, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMalloc(&ce->ctxh, n * CE_H * 4);
+    // (rows past a call's last token are read by the last tile's LDS-DMA and never stored: defined bits, once)
+    if (e == hipSuccess) e = hipMemset(ce->hx, 0, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMemset(ce->ctxh, 0, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMemset(ce->inter32, 0, n * CE_FFN * 4);
     if (e != hipSuccess) { rr_set_error("rr_ce_forward: fp32 activation scratch for %lld tokens: %s", (long long)tokens, hipGetErrorString(e)); return RR_E_NOMEM; }
     ce->cap32 = (int64_t)n;
     return RR_OK;
@@ -1884,10 +1942,79 @@ static int ce_reserve_f32(rr_ce* ce, int64_t tokens) {
 
 // the forward pass of RR_CE_PRECISION_F32 (every operand fp32): embeddings -> per layer QKV, attention, output projection
 // + residual + LayerNorm, FFN (exact GELU) + residual + LayerNorm -> head
+static int ce_reserve_seqs_f32(rr_ce* ce, int64_t seqs) {
+    if (seqs <= ce->cap32_seqs) return RR_OK;
+    RR_HIP_TRY(hipDeviceSynchronize());
+    hipFree(ce->h32c32); hipFree(ce->y32c); hipFree(ce->hxc); hipFree(ce->ctxhc); hipFree(ce->interhc);
+    ce->h32c32 = ce->y32c = nullptr;
+    ce->hxc = ce->ctxhc = ce->interhc = nullptr;
+    ce->cap32_seqs = 0;
+    const size_t n = (size_t)rr_round_up(seqs, 1024);
+    hipError_t e = hipMalloc((void**)&ce->h32c32, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&ce->y32c, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMalloc(&ce->hxc, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMalloc(&ce->ctxhc, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMalloc(&ce->interhc, n * CE_FFN * 4);
+    if (e == hipSuccess) e = hipMemset(ce->hxc, 0, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMemset(ce->ctxhc, 0, n * CE_H * 4);
+    if (e == hipSuccess) e = hipMemset(ce->interhc, 0, n * CE_FFN * 4);
+    if (e != hipSuccess) { rr_set_error("rr_ce_forward: compact fp32 scratch for %lld sequences: %s", (long long)seqs, hipGetErrorString(e)); return RR_E_NOMEM; }
+    ce->cap32_seqs = (int64_t)n;
+    return RR_OK;
+}
+
+// ... the same forward on the fp16 matrix cores (rr_ce_h2.hip): every GEMM operand an h2 image written by its producer
+static int ce_forward_h2(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_type_ids, const int32_t* d_pos_ids,
+                         const int32_t* d_cu_seqlens, int n_seqs, int T, int max_len, int mode, float* d_out, hipStream_t st) {
+    const int64_t xs = ce->cap32;
+    if (mode != RR_CE_OUT_HIDDEN) {
+        const int rc = ce_reserve_seqs_f32(ce, n_seqs);
+        if (rc) return rc;
+    }
+    const int64_t xc = ce->cap32_seqs;
+    RR_HIP_TRY(hipMemsetAsync(ce->d_flag, 0, 4, st));
+    ce_h2_embed_ln(d_token_ids, d_type_ids, d_pos_ids, T, ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type,
+                   ce->eln_g, ce->eln_b, ce->cfg.ln_eps, ce->h32, ce->hx, xs, ce->d_flag, st);
+    for (int l = 0; l < ce->cfg.n_layers; ++l) {
+        const rr_ce_layer& L = ce->layers[l];
+        ce_h2_gemm(CE_H2_EPI_F32, L.wqkv_h2, 3 * CE_H, ce->hx, xs, T, CE_H, L.bqkv, ce->qkv32, nullptr, 0, ce->d_flag, st);
+        if (l == ce->cfg.n_layers - 1 && mode != RR_CE_OUT_HIDDEN) {
+            // The last layer of a [CLS]-pooled output needs keys and values of every token but only the [CLS] query row (as
+            // the bf16 path below): attention for that row alone, everything behind it on one compact row per sequence.
+            hipLaunchKernelGGL(ce_attention_x3<true>, dim3((unsigned)n_seqs, CE_HEADS), dim3(512), CE_X3A_LDS, st, ce->qkv32, d_cu_seqlens,
+                               (float*)nullptr, 0.17677669529663687f, (u32x2*)ce->ctxhc, xc, ce->d_flag, 1);
+            hipLaunchKernelGGL(ce_gather_cls, dim3((unsigned)n_seqs), dim3(128), 0, st, ce->h32, d_cu_seqlens, ce->h32c32);
+            ce_h2_gemm(CE_H2_EPI_F32, L.wo_h2, CE_H, ce->ctxhc, xc, n_seqs, CE_H, L.bo, ce->y32c, nullptr, 0, ce->d_flag, st);
+            ce_h2_add_ln(ce->y32c, ce->h32c32, n_seqs, L.ln1_g, L.ln1_b, ce->cfg.ln_eps, ce->hxc, xc, ce->d_flag, st);
+            ce_h2_gemm(CE_H2_EPI_GELU_H2, L.w1_h2, CE_FFN, ce->hxc, xc, n_seqs, CE_H, L.b1, nullptr, ce->interhc, xc, ce->d_flag, st);
+            ce_h2_gemm(CE_H2_EPI_F32, L.w2_h2, CE_H, ce->interhc, xc, n_seqs, CE_FFN, L.b2, ce->y32c, nullptr, 0, ce->d_flag, st);
+            ce_h2_add_ln(ce->y32c, ce->h32c32, n_seqs, L.ln2_g, L.ln2_b, ce->cfg.ln_eps, ce->hxc, xc, ce->d_flag, st);
+            hipLaunchKernelGGL(ce_head, dim3((unsigned)n_seqs), dim3(256), 0, st, ce->h32c32, (const int32_t*)nullptr, ce->wp, ce->bp, ce->wc,
+                               ce->bc, ce->cfg.n_labels, mode, d_out);
+            return RR_OK;
+        }
+        hipLaunchKernelGGL(ce_attention_x3<true>, dim3((unsigned)n_seqs, CE_HEADS), dim3(512), CE_X3A_LDS, st, ce->qkv32, d_cu_seqlens,
+                           (float*)nullptr, 0.17677669529663687f /* 1 / sqrt(32) */, (u32x2*)ce->ctxh, xs, ce->d_flag, 0);
+        ce_h2_gemm(CE_H2_EPI_F32, L.wo_h2, CE_H, ce->ctxh, xs, T, CE_H, L.bo, ce->y32, nullptr, 0, ce->d_flag, st);
+        ce_h2_add_ln(ce->y32, ce->h32, T, L.ln1_g, L.ln1_b, ce->cfg.ln_eps, ce->hx, xs, ce->d_flag, st);
+        ce_h2_gemm(CE_H2_EPI_GELU_H2, L.w1_h2, CE_FFN, ce->hx, xs, T, CE_H, L.b1, nullptr, ce->inter32, xs, ce->d_flag, st);
+        ce_h2_gemm(CE_H2_EPI_F32, L.w2_h2, CE_H, ce->inter32, xs, T, CE_FFN, L.b2, ce->y32, nullptr, 0, ce->d_flag, st);
+        ce_h2_add_ln(ce->y32, ce->h32, T, L.ln2_g, L.ln2_b, ce->cfg.ln_eps, ce->hx, xs, ce->d_flag, st);
+    }
+    // (mode != RR_CE_OUT_HIDDEN left through the last layer's [CLS] tail above)
+    RR_HIP_TRY(hipMemcpyAsync(d_out, ce->h32, sizeof(float) * (size_t)T * CE_H, hipMemcpyDeviceToDevice, st));
+    (void)max_len;
+    return RR_OK;
+}
+
 static int ce_forward_f32(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_type_ids, const int32_t* d_pos_ids,
                           const int32_t* d_cu_seqlens, int n_seqs, int T, int max_len, int mode, float* d_out, hipStream_t st) {
     int rc = ce_reserve_f32(ce, T);
     if (rc) return rc;
+    // RR_CE_F32_SPLIT=bf16x3 (A/B) or rr_ce_set_wide_range: three bf16 terms per operand, six products -- any fp32 range
+    static const bool split_bf16 = getenv("RR_CE_F32_SPLIT") != nullptr && strcmp(getenv("RR_CE_F32_SPLIT"), "bf16x3") == 0;
+    if (!split_bf16 && !ce->wide_range && getenv("RR_CE_F32_MFMA") == nullptr && getenv("RR_CE_F32_ATT_MFMA32") == nullptr)
+        return ce_forward_h2(ce, d_token_ids, d_type_ids, d_pos_ids, d_cu_seqlens, n_seqs, T, max_len, mode, d_out, st);
     hipLaunchKernelGGL(ce_embed_ln, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, d_token_ids, d_type_ids, d_pos_ids, T,
                        ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type, ce->eln_g, ce->eln_b,
                        ce->cfg.ln_eps, ce->h32, ce->hb);
@@ -1903,8 +2030,8 @@ static int ce_forward_f32(rr_ce* ce, const int32_t* d_token_ids, const int32_t* 
             hipLaunchKernelGGL(ce_attention_f32, dim3((unsigned)n_seqs, CE_HEADS), dim3(256), att_lds, st, ce->qkv32, d_cu_seqlens, ce->y32,
                                0.17677669529663687f /* 1 / sqrt(32) */);
         else
-            hipLaunchKernelGGL(ce_attention_x3, dim3((unsigned)n_seqs, CE_HEADS), dim3(512), CE_X3A_LDS, st, ce->qkv32, d_cu_seqlens, ce->y32,
-                               0.17677669529663687f /* 1 / sqrt(32) */);
+            hipLaunchKernelGGL(ce_attention_x3<false>, dim3((unsigned)n_seqs, CE_HEADS), dim3(512), CE_X3A_LDS, st, ce->qkv32, d_cu_seqlens, ce->y32,
+                               0.17677669529663687f /* 1 / sqrt(32) */, (u32x2*)nullptr, (int64_t)0, (unsigned*)nullptr, 0);
         // (y32 holds the context; the projection's output goes to the first T x 384 floats of inter32)
         if (f32_x3) hipLaunchKernelGGL((ce_gemm_x3<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->y32, L.wo32, L.bo, T, CE_H, CE_H, ce->inter32);
         else hipLaunchKernelGGL((ce_gemm_f32<false>), dim3(CE_H / 128, mt), dim3(256), 0, st, ce->y32, L.wo32, L.bo, T, CE_H, CE_H, ce->inter32);

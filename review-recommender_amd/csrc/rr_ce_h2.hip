@@ -1,0 +1,380 @@
+// rr_ce_h2.hip -- K5, reference-precision mode (RR_CE_PRECISION_F32) on the fp16 matrix cores.
+//
+// The reference runs both encoders in fp32 torch (app/app_product_search.py:250-251, 277-278).  An fp32 product needs 24 x 24
+// significand bits; fp16 carries 11, so x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048) holds 22-23 bits of x
+// (the subtraction is exact; the scale keeps lo a normal fp16 down to |x - hi| = 3e-8), and
+//     x * y  =  hi_x hi_y  +  (hi_x lo_y + lo_x hi_y) / 2048  +  O(2^-22 x y)
+// is three v_mfma_f32_16x16x32_f16 instead of the six bf16 products of ce_gemm_x3 (rr_ce.hip): the first into one fp32
+// accumulator, the two cross terms into a second one that is scaled by 2^-11 once, in the epilogue.  What is dropped (lo lo,
+// 2^-22) is a quarter of the rounding of ONE fp32 multiply-add chain's noise: on N(0,1) x N(0, 0.05^2) operands, K = 384 or
+// 1536, the result sits 9.4e-8 (rms, relative) from the exact product against 4.4e-7 for an fp32 GEMM (numpy sgemm) --
+// tests/test_gpu_k5.py holds the whole forward to the same 1e-5 / 5e-6 bars as before.  fp16's range is the price: a value
+// beyond 65504 cannot be split; every producer ORs a flag when it meets one and the host reruns that forward on the bf16
+// three-term kernels (rr_ce.hip: ce_gemm_x3 / ce_attention_x3, any fp32 range).
+//
+// Operands travel as "h2" images (rr_ce_h2.h): two fp16 planes in 16-byte units of eight k, chunk-major, written by the
+// PRODUCER's epilogue (LayerNorm, GELU, attention) -- a value is split once, not once per column block that reads it, and an h2
+// image is exactly as large as the fp32 matrix.  For ce_gemm_h2 that layout makes a 64-row x 8-k piece of a tile 1 KiB that
+// is contiguous in HBM and in LDS: the tiles are staged by LDS-DMA (global_load_lds_dwordx4, no registers, no ds_write), three
+// K steps deep, and an MFMA operand fragment is one conflict-free ds_read_b128.
+#include "rr_ce_h2.h"
+
+#include <cmath>
+
+#include "rr_common.h"
+
+typedef _Float16 h2_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_f16x4 __attribute__((ext_vector_type(4)));
+typedef float h2_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int h2_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int h2_u32x2 __attribute__((ext_vector_type(2)));
+
+#define H2_H 384
+
+struct h2_pair { _Float16 hi, lo; };
+__device__ __forceinline__ h2_pair h2_split(float x) {
+    h2_pair r;
+    // nearest even; a value whose hi would be a SUBNORMAL fp16 (the matrix cores flush those on input) goes to lo whole:
+    // |x| < 2^-14 is x * 2048 < 2^-3, eleven bits of it
+    r.hi = __builtin_fabsf(x) < 6.103515625e-05f ? (_Float16)0.f : (_Float16)x;
+    r.lo = (_Float16)((x - (float)r.hi) * CE_H2_SCALE);         // (exact difference; |.| * 2048 <= |x|)
+    return r;
+}
+__device__ __forceinline__ bool h2_out_of_range(float x) { return !(__builtin_fabsf(x) <= 65504.f); }    // (NaN too)
+__device__ __forceinline__ void h2_raise(bool bad, unsigned* flag) {
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+__device__ __forceinline__ float h2_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------ fp32 rows -> h2 (weights, at load)
+__global__ __launch_bounds__(256) void ce_h2_pack_kernel(const float* __restrict__ src, int R, int K, h2_u32x4* __restrict__ dst,
+                                                         int64_t rs) {
+    const int KC = K >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // unit (kc, row), rows fastest
+    if (i >= (int64_t)R * KC) return;
+    const int row = (int)(i % R), kc = (int)(i / R);
+    const float* p = src + (int64_t)row * K + 8 * kc;
+    h2_f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const h2_pair s = h2_split(p[e]);
+        hi[e] = s.hi;
+        lo[e] = s.lo;
+    }
+    dst[(int64_t)kc * rs + row] = __builtin_bit_cast(h2_u32x4, hi);
+    dst[((int64_t)KC + kc) * rs + row] = __builtin_bit_cast(h2_u32x4, lo);
+}
+
+void ce_h2_pack(const float* d_src, int R, int K, void* d_dst, int64_t row_stride, hipStream_t st) {
+    const int64_t n = (int64_t)R * (K / 8);
+    hipLaunchKernelGGL(ce_h2_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_src, R, K, (h2_u32x4*)d_dst, row_stride);
+}
+
+// ------------------------------------------------------------------ LayerNorm producers
+// Workgroup = 32 tokens, a wave takes eight of them one after the other (lane c < 48 = chunk c: 32 bytes of the fp32 row).
+// The h2 units of the 32 tokens are gathered in LDS ([plane][chunk][token], token rows padded to 33 units) and leave as 512-byte
+// runs of 32 consecutive tokens per (plane, chunk): written straight from the lanes they would be 16-byte pieces 16 * xs bytes
+// apart (measured: 287 us per launch at 131 072 tokens against 100 for this form).
+#define H2LN_TOK 32
+#define H2LN_LD 33
+template <bool EMBED>
+__global__ __launch_bounds__(256) void ce_h2_ln_kernel(const int32_t* __restrict__ tok, const int32_t* __restrict__ typ,
+                                                       const int32_t* __restrict__ pos, int T, int vocab, int n_pos, int n_typ,
+                                                       const float* __restrict__ we, const float* __restrict__ pe,
+                                                       const float* __restrict__ te, const float* __restrict__ y,
+                                                       const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                       float* __restrict__ h32, h2_u32x4* __restrict__ hx, int64_t xs,
+                                                       unsigned* __restrict__ flag) {
+    __shared__ h2_u32x4 img[2 * 48 * H2LN_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tb = blockIdx.x * H2LN_TOK;
+    const bool on = lane < 48;
+    const int c8 = 8 * (on ? lane : 0);
+    h2_f32x4 gg[2], bb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        gg[h] = *reinterpret_cast<const h2_f32x4*>(g + c8 + 4 * h);
+        bb[h] = *reinterpret_cast<const h2_f32x4*>(b + c8 + 4 * h);
+    }
+    bool bad = false;
+    for (int i8 = 0; i8 < 8; ++i8) {
+        const int tl = 8 * wave + i8, t = tb + tl;
+        if (t >= T) break;                                   // (wave-uniform)
+        float x[8];
+        if (EMBED) {
+            int id = tok[t], ty = typ[t], po = pos[t];
+            id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // ids are validated on the host; stay in bounds anyway
+            ty = ty < 0 ? 0 : (ty >= n_typ ? n_typ - 1 : ty);
+            po = po < 0 ? 0 : (po >= n_pos ? n_pos - 1 : po);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const h2_f32x4 a = *reinterpret_cast<const h2_f32x4*>(we + (int64_t)id * H2_H + c8 + 4 * h);
+                const h2_f32x4 d = *reinterpret_cast<const h2_f32x4*>(te + (int64_t)ty * H2_H + c8 + 4 * h);
+                const h2_f32x4 e = *reinterpret_cast<const h2_f32x4*>(pe + (int64_t)po * H2_H + c8 + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[4 * h + i] = (a[i] + d[i]) + e[i];      // (the order of BertEmbeddings: word + type, + position)
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const h2_f32x4 a = *reinterpret_cast<const h2_f32x4*>(y + (int64_t)t * H2_H + c8 + 4 * h);
+                const h2_f32x4 d = *reinterpret_cast<const h2_f32x4*>(h32 + (int64_t)t * H2_H + c8 + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[4 * h + i] = a[i] + d[i];
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += on ? x[i] : 0.f;
+        const float mean = h2_wave_sum(s) * (1.f / H2_H);
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = x[i] - mean; v += on ? d * d : 0.f; }
+        const float var = h2_wave_sum(v) * (1.f / H2_H) + eps;
+        const float rstd = EMBED ? rsqrtf(var) : 1.0f / sqrtf(var);     // (as ce_embed_ln / ce_add_ln_f32, rr_ce.hip)
+        h2_f16x8 hi, lo;
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float r = (x[i] - mean) * rstd * gg[i >> 2][i & 3] + bb[i >> 2][i & 3];
+            o[i] = r;
+            const h2_pair p = h2_split(r);
+            hi[i] = p.hi;
+            lo[i] = p.lo;
+            bad |= h2_out_of_range(r);
+        }
+        if (on) {
+            *reinterpret_cast<h2_f32x4*>(h32 + (int64_t)t * H2_H + c8) = h2_f32x4{o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<h2_f32x4*>(h32 + (int64_t)t * H2_H + c8 + 4) = h2_f32x4{o[4], o[5], o[6], o[7]};
+            img[lane * H2LN_LD + tl] = __builtin_bit_cast(h2_u32x4, hi);
+            img[(48 + lane) * H2LN_LD + tl] = __builtin_bit_cast(h2_u32x4, lo);
+        }
+    }
+    h2_raise(on && bad, flag);
+    __syncthreads();
+    for (int i = tid; i < 2 * 48 * H2LN_TOK; i += 256) {
+        const int pc = i >> 5, tl = i & 31;
+        if (tb + tl < T) hx[(int64_t)pc * xs + tb + tl] = img[pc * H2LN_LD + tl];
+    }
+}
+
+void ce_h2_embed_ln(const int32_t* tok, const int32_t* typ, const int32_t* pos, int T, int vocab, int n_pos, int n_typ,
+                    const float* we, const float* pe, const float* te, const float* g, const float* b, float eps, float* h32,
+                    void* hx, int64_t xs, unsigned* flag, hipStream_t st) {
+    hipLaunchKernelGGL((ce_h2_ln_kernel<true>), dim3((unsigned)((T + H2LN_TOK - 1) / H2LN_TOK)), dim3(256), 0, st, tok, typ, pos, T, vocab, n_pos,
+                       n_typ, we, pe, te, (const float*)nullptr, g, b, eps, h32, (h2_u32x4*)hx, xs, flag);
+}
+
+void ce_h2_add_ln(const float* y, float* h32, int T, const float* g, const float* b, float eps, void* hx, int64_t xs,
+                  unsigned* flag, hipStream_t st) {
+    hipLaunchKernelGGL((ce_h2_ln_kernel<false>), dim3((unsigned)((T + H2LN_TOK - 1) / H2LN_TOK)), dim3(256), 0, st, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, T, 0, 0, 0, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, y, g, b, eps, h32, (h2_u32x4*)hx, xs, flag);
+}
+
+// ------------------------------------------------------------------ GEMM
+// Workgroup = 8 waves, tile = 128 features x 256 tokens, wave (wf = w & 1, wt = w >> 1) = 64 features x 64 tokens = 4 x 4
+// MFMA tiles, two accumulators (128 registers); two waves per SIMD, one workgroup per CU.  The MFMA computes the TRANSPOSED
+// tile, D[feature][token] = W X^T (A operand = the weights): a lane then holds four consecutive FEATURES of one token --
+// 16 bytes of an fp32 row, or the 8-byte half of an h2 unit.  (CE_H2_EPI_VT swaps the operands, D[token][feature]: four
+// consecutive tokens of one feature, what the V^T image wants.)
+// K step = 32 = one MFMA depth; per step a stage of LDS holds W [plane][chunk][128 rows] (16 KB) and X [plane][chunk][256 rows]
+// (32 KB) in units: 48 LDS-DMA pieces of 64 rows, six per wave.  Three stages: the pieces of step s + 2 are issued right
+// after the barrier of step s (every wave has read stage s - 1 by then), `s_waitcnt vmcnt(6)` + the barrier make stage s
+// visible.  Fragment of lane (r = l & 15, kq = l >> 4): unit [plane][kq][tile row r]: a ds_read_b128 is served in four groups
+// of 16 lanes that hold 16 different rows r each (MI355X_MICROARCH.md, LDS) = 16 different 16-byte bank groups: no conflict.
+// Grid: 1-D, XCD-aware -- workgroup id % 8 is the XCD; the feature blocks of one token block run on ONE XCD back to back, so
+// the token tile is fetched from HBM once and re-read from that XCD's L2.
+#define H2G_BT 256
+#define H2G_BF 128
+#define H2G_STAGE_UNITS 3072
+#define H2G_STAGES 3
+#define H2G_LDS (H2G_STAGES * H2G_STAGE_UNITS * 16)
+
+#define H2_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+
+__device__ __forceinline__ float h2_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict__ W2, int N, const h2_u32x4* __restrict__ X2, int64_t xs,
+                                                     int M, int K, const float* __restrict__ bias, float* __restrict__ out32,
+                                                     h2_u32x2* __restrict__ out2, int64_t os, unsigned* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) h2_u32x4 h2g_lds[];
+    constexpr bool SWAP = EPI == CE_H2_EPI_VT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nf = N / H2G_BF;
+    const int id = blockIdx.x, slot = id >> 3;
+    const int tb = (slot / nf) * 8 + (id & 7), fb = slot % nf;
+    const int m0 = tb * H2G_BT, n0 = fb * H2G_BF;
+    if (m0 >= M) return;                                   // (whole workgroup: the grid is padded to eight token blocks)
+    const int KC = K >> 3, KS = K >> 5;
+
+    // ---- LDS-DMA pieces of this wave: g = 6 w + j; g < 16: W piece (plane-chunk g >> 1, row half g & 1), else X piece
+    const h2_u32x4* src[6];
+    int64_t step[6];
+    int dst[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int g = 6 * w + j;
+        if (g < 16) {
+            const int pc = g >> 1, half = g & 1;
+            src[j] = W2 + ((int64_t)((pc >> 2) * KC + (pc & 3)) * N + n0 + 64 * half + lane);
+            step[j] = 4 * (int64_t)N;
+            dst[j] = pc * 128 + 64 * half;
+        } else {
+            const int pc = (g - 16) >> 2, q = (g - 16) & 3;
+            src[j] = X2 + ((int64_t)((pc >> 2) * KC + (pc & 3)) * xs + m0 + 64 * q + lane);
+            step[j] = 4 * xs;
+            dst[j] = 1024 + pc * 256 + 64 * q;
+        }
+    }
+    auto issue = [&](int s, int buf) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            __builtin_amdgcn_global_load_lds(src[j] + s * step[j],
+                                             (__attribute__((address_space(3))) void*)(h2g_lds + buf * H2G_STAGE_UNITS + dst[j]), 16, 0, 0);
+    };
+    const int r = lane & 15, kq = lane >> 4, wf = w & 1, wt = w >> 1;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)h2g_lds;
+    const uint32_t aW = lds0 + 16u * (uint32_t)(kq * 128 + 64 * wf + r);
+    const uint32_t aX = lds0 + 16u * (uint32_t)(1024 + kq * 256 + 64 * wt + r);
+
+    h2_f32x4 acc1[4][4], acc2[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc1[i][j] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
+            acc2[i][j] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    issue(0, 0);
+    if (KS > 1) issue(1, 1);
+    int buf = 0;
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < KS) issue(s + 2, buf >= 1 ? buf - 1 : 2);         // (s + 2) % 3
+        const uint32_t bW = aW + (uint32_t)buf * (H2G_STAGE_UNITS * 16), bX = aX + (uint32_t)buf * (H2G_STAGE_UNITS * 16);
+        h2_u32x4 wh[4], wl[4], xh[4], xl[4];
+        H2_READ(wh[0], bW, 0); H2_READ(wh[1], bW, 256); H2_READ(wh[2], bW, 512); H2_READ(wh[3], bW, 768);
+        H2_READ(xh[0], bX, 0); H2_READ(xh[1], bX, 256); H2_READ(xh[2], bX, 512); H2_READ(xh[3], bX, 768);
+        H2_READ(xl[0], bX, 16384); H2_READ(xl[1], bX, 16384 + 256); H2_READ(xl[2], bX, 16384 + 512); H2_READ(xl[3], bX, 16384 + 768);
+        H2_READ(wl[0], bW, 8192); H2_READ(wl[1], bW, 8192 + 256); H2_READ(wl[2], bW, 8192 + 512); H2_READ(wl[3], bW, 8192 + 768);
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(wh[0]), "+v"(wh[1]), "+v"(wh[2]), "+v"(wh[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]) :: "memory");
+#define H2_MFMA(A, B, C) \
+    C = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h2_f16x8, B), __builtin_bit_cast(h2_f16x8, A), C, 0, 0, 0) \
+             : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h2_f16x8, A), __builtin_bit_cast(h2_f16x8, B), C, 0, 0, 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) H2_MFMA(wh[i], xh[j], acc1[i][j]);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]) :: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) H2_MFMA(wh[i], xl[j], acc2[i][j]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wl[0]), "+v"(wl[1]), "+v"(wl[2]), "+v"(wl[3]) :: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) H2_MFMA(wl[i], xh[j], acc2[i][j]);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    // ---- epilogue
+    bool bad = false;
+    if (!SWAP) {
+        // acc[i][j][e]: feature n0 + 64 wf + 16 i + 4 kq + e, token m0 + 64 wt + 16 j + r
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = n0 + 64 * wf + 16 * i + 4 * kq;
+            const h2_f32x4 bv = *reinterpret_cast<const h2_f32x4*>(bias + f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = m0 + 64 * wt + 16 * j + r;
+                h2_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = __builtin_fmaf(acc2[i][j][e], CE_H2_INV_SCALE, acc1[i][j][e]) + bv[e];
+                    if (EPI == CE_H2_EPI_GELU_H2) v[e] = h2_gelu_erf(v[e]);
+                }
+                if (t >= M) continue;
+                if (EPI == CE_H2_EPI_F32) {
+                    *reinterpret_cast<h2_f32x4*>(out32 + (int64_t)t * N + f) = v;
+                } else {
+                    h2_f16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const h2_pair p = h2_split(v[e]);
+                        hi[e] = p.hi;
+                        lo[e] = p.lo;
+                        bad |= h2_out_of_range(v[e]);
+                    }
+                    const int64_t u = (int64_t)(f >> 3) * os + t;                  // unit (chunk f / 8, token), half kq & 1
+                    out2[2 * u + (kq & 1)] = __builtin_bit_cast(h2_u32x2, hi);
+                    out2[2 * ((int64_t)(N >> 3) * os + u) + (kq & 1)] = __builtin_bit_cast(h2_u32x2, lo);
+                }
+            }
+        }
+    } else {
+        // acc[i][j][e]: token m0 + 64 wt + 16 j + 4 kq + e, feature (= dim) n0 + 64 wf + 16 i + r.  V^T image: unit
+        // (plane, 32-token group g, dim, q) at ((plane * G + g) * N + dim) * 4 + q, G = os / 32, holds the EIGHT k slots
+        // 8 q + 4 a + e  <->  token 32 g + 16 a + 4 q + e (a = 0, 1): the order ce_attention_h2's probabilities sit in.
+        // Tokens past M are written as zeros (their group may be read, with probability 0).
+        const int64_t G = os >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = n0 + 64 * wf + 16 * i + r;
+            const float bv = bias[d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tq = m0 + 64 * wt + 16 * j + 4 * kq;
+                h2_f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = __builtin_fmaf(acc2[i][j][e], CE_H2_INV_SCALE, acc1[i][j][e]) + bv;
+                    v = tq + e < M ? v : 0.f;
+                    const h2_pair p = h2_split(v);
+                    hi[e] = p.hi;
+                    lo[e] = p.lo;
+                    bad |= h2_out_of_range(v);
+                }
+                const int64_t g = tq >> 5;
+                const int a = (tq >> 4) & 1;
+                const int64_t u = ((g * N + d) << 2) + kq;
+                out2[2 * u + a] = __builtin_bit_cast(h2_u32x2, hi);
+                out2[2 * ((G * N << 2) + u) + a] = __builtin_bit_cast(h2_u32x2, lo);
+            }
+        }
+    }
+    if (EPI != CE_H2_EPI_F32) h2_raise(bad, flag);
+}
+
+int ce_h2_set_attributes() {
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_H2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_GELU_H2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_VT>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
+    return RR_OK;
+}
+
+void ce_h2_gemm(int epi, const void* W2, int N, const void* X2, int64_t xs, int M, int K, const float* bias, float* out32,
+                void* out2, int64_t os, unsigned* flag, hipStream_t st) {
+    const int tbs = (M + H2G_BT - 1) / H2G_BT;
+    const dim3 grid((unsigned)(((tbs + 7) / 8) * 8 * (N / H2G_BF)));
+#define H2_LAUNCH(E) \
+    hipLaunchKernelGGL((ce_gemm_h2<E>), grid, dim3(512), H2G_LDS, st, (const h2_u32x4*)W2, N, (const h2_u32x4*)X2, xs, M, K, bias, out32, \
+                       (h2_u32x2*)out2, os, flag)
+    if (epi == CE_H2_EPI_F32) H2_LAUNCH(CE_H2_EPI_F32);
+    else if (epi == CE_H2_EPI_H2) H2_LAUNCH(CE_H2_EPI_H2);
+    else if (epi == CE_H2_EPI_GELU_H2) H2_LAUNCH(CE_H2_EPI_GELU_H2);
+    else H2_LAUNCH(CE_H2_EPI_VT);
+#undef H2_LAUNCH
+}
