@@ -263,7 +263,10 @@ class SyntheticPairScorer:
             out[s0:s0 + m] = logits[:, 0]
             self.tokens += int(cu[-1].item())
         self.pairs += n
-        return out.cpu().numpy()
+        res = out.cpu().numpy()
+        if not np.isfinite(res).all():                             # (NaN logits = the encoder's fp16-range flag, include/rr_hip.h)
+            raise RuntimeError("cross-encoder logits are not finite: rr_ce_range_status / set_wide_range")
+        return res
 
 
 def main():

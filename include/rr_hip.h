@@ -304,6 +304,14 @@ int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d_ty
                       float* d_out, void* stream);
 /* HIP-event time of the last forward pass on this handle (ms). */
 int rr_ce_last_forward_ms(rr_ce* ce, float* out_ms);
+/* RR_CE_PRECISION_F32 multiplies on the fp16 matrix cores: every fp32 operand as hi + lo / 2048 in two fp16 numbers, three
+ * products per fp32 product (csrc/rr_ce_h2.hip; as exact as an fp32 multiply-add chain).  fp16 ends at 65504: a forward pass
+ * that meets a larger activation raises a flag on the device, writes NaN logits / CLS rows for the whole call (never a wrong
+ * finite number) and reports it here -- *out_of_range = 1 -- once the pass has finished (this call waits for it).
+ * rr_ce_set_wide_range(ce, 1) switches the handle to three bf16 terms per operand and six products (any fp32 range,
+ * ~1.6 x the time): run the pass again after it.  cross_encoder.py does both by itself on the host path. */
+int rr_ce_range_status(rr_ce* ce, int32_t* out_of_range);
+int rr_ce_set_wide_range(rr_ce* ce, int32_t on);
 
 /* Two-phase K1 for ROW SHARDS (sharded.py: one process per GPU, this shard's rows in `ix`).  A shard's
  * own top-`top_k` threshold sits far below the corpus-wide one (rank 150 of 1.25M rows ~ rank 1 200 of 10M), so a shard

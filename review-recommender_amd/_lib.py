@@ -86,6 +86,8 @@ PROTOTYPES = {
     "rr_ce_destroy": (C.c_int, [c_vp]),
     "rr_ce_forward_dev": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "rr_ce_last_forward_ms": (C.c_int, [c_vp, P(c_f32)]),
+    "rr_ce_range_status": (C.c_int, [c_vp, P(C.c_int32)]),
+    "rr_ce_set_wide_range": (C.c_int, [c_vp, C.c_int32]),
     "rr_index_stream": (C.c_int, [c_vp, P(c_vp)]),
     "rr_index_synchronize": (C.c_int, [c_vp]),
 }

@@ -157,6 +157,15 @@ class BertEncoderGPU:
                     C.c_void_p(d_out.data_ptr()), C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)),
                     "rr_ce_forward_dev")
                 res = d_out.cpu().numpy()
+                if self.precision == "fp32" and self.out_of_range():
+                    # an activation beyond fp16's 65504 (csrc/rr_ce_h2.hip): this handle continues on the wide-range kernels
+                    self.set_wide_range(True)
+                    _lib.check(lib.rr_ce_forward_dev(
+                        self._h, C.c_void_p(base), C.c_void_p(base + 4 * tot), C.c_void_p(base + 8 * tot),
+                        C.c_void_p(base + 12 * tot), len(part), tot, int(lens[start:end].max()), mode,
+                        C.c_void_p(d_out.data_ptr()), C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)),
+                        "rr_ce_forward_dev")
+                    res = d_out.cpu().numpy()
             if mode == OUT_HIDDEN:
                 out[tok_done:tok_done + tot] = res
             else:
@@ -178,6 +187,23 @@ class BertEncoderGPU:
             self._h, p(tok), p(typ), p(pos), p(cu), int(n_seqs), n_tokens, int(max_len), mode, p(out),
             C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)), "rr_ce_forward_dev")
         return out
+
+    def out_of_range(self) -> bool:
+        """True when the LAST forward pass (waited for here) met a value beyond fp16's range: its logits / CLS rows are NaN
+        (include/rr_hip.h: rr_ce_range_status).  `forward_ids` checks and reruns by itself; a caller of
+        `forward_packed_dev` checks after it has synchronised, calls `set_wide_range(True)` and submits the batch again."""
+        flag = C.c_int32()
+        _lib.check(_lib.load().rr_ce_range_status(self._h, C.byref(flag)), "rr_ce_range_status")
+        return bool(flag.value)
+
+    def set_wide_range(self, on: bool = True) -> None:
+        """fp32 precision only: three bf16 terms per operand and six products (any fp32 range) instead of two fp16 terms
+        and three."""
+        if on and not getattr(self, "_warned_wide", False):
+            import warnings
+            warnings.warn("encoder activations exceed the fp16 range: this handle switches to the bf16 three-term kernels")
+            self._warned_wide = True
+        _lib.check(_lib.load().rr_ce_set_wide_range(self._h, 1 if on else 0), "rr_ce_set_wide_range")
 
     def last_forward_ms(self) -> float:
         ms = C.c_float()

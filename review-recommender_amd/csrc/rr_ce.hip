@@ -1063,9 +1063,14 @@ __global__ __launch_bounds__(CE_ATT_THREADS, 2) void ce_attention(const unsigned
 __global__ __launch_bounds__(256) void ce_head(const float* __restrict__ h32, const int32_t* __restrict__ cu,
                                                const float* __restrict__ wp, const float* __restrict__ bp,
                                                const float* __restrict__ wc, const float* __restrict__ bc, int n_labels,
-                                               int mode, float* __restrict__ out) {
+                                               int mode, float* __restrict__ out, const unsigned* __restrict__ range_flag = nullptr) {
     __shared__ float x[CE_H], pooled[CE_H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, seq = blockIdx.x;
+    if (range_flag && *range_flag) {                       // (rr_ce_h2.hip: a value left the fp16 range: no finite answer)
+        const int n = mode == 1 ? CE_H : n_labels;
+        for (int c = tid; c < n; c += 256) out[(int64_t)seq * n + c] = __builtin_nanf("");
+        return;
+    }
     const float* src = h32 + (int64_t)(cu ? cu[seq] : seq) * CE_H;       // cu == null: h32 is compact, one row per sequence
     for (int c = tid; c < CE_H; c += 256) x[c] = src[c];
     __syncthreads();
@@ -1935,6 +1940,7 @@ static int ce_reserve_f32(rr_ce* ce, int64_t tokens) {
     if (e == hipSuccess) e = hipMemset(ce->hx, 0, n * CE_H * 4);
     if (e == hipSuccess) e = hipMemset(ce->ctxh, 0, n * CE_H * 4);
     if (e == hipSuccess) e = hipMemset(ce->inter32, 0, n * CE_FFN * 4);
+    if (e == hipSuccess) e = hipMemset(ce->qkv32, 0, n * 3 * CE_H * 4);
     if (e != hipSuccess) { rr_set_error("rr_ce_forward: fp32 activation scratch for %lld tokens: %s", (long long)tokens, hipGetErrorString(e)); return RR_E_NOMEM; }
     ce->cap32 = (int64_t)n;
     return RR_OK;
@@ -1972,17 +1978,28 @@ static int ce_forward_h2(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d
         if (rc) return rc;
     }
     const int64_t xc = ce->cap32_seqs;
-    RR_HIP_TRY(hipMemsetAsync(ce->d_flag, 0, 4, st));
     ce_h2_embed_ln(d_token_ids, d_type_ids, d_pos_ids, T, ce->cfg.vocab, ce->cfg.max_pos, ce->cfg.type_vocab, ce->word, ce->pos, ce->type,
                    ce->eln_g, ce->eln_b, ce->cfg.ln_eps, ce->h32, ce->hx, xs, ce->d_flag, st);
     for (int l = 0; l < ce->cfg.n_layers; ++l) {
         const rr_ce_layer& L = ce->layers[l];
-        ce_h2_gemm(CE_H2_EPI_F32, L.wqkv_h2, 3 * CE_H, ce->hx, xs, T, CE_H, L.bqkv, ce->qkv32, nullptr, 0, ce->d_flag, st);
-        if (l == ce->cfg.n_layers - 1 && mode != RR_CE_OUT_HIDDEN) {
+        // QKV as ONE h2 image of [T][1152] inside the qkv32 allocation (Q scaled by log2 e / sqrt 32);
+        // RR_CE_H2_ATT_X3=1 (A/B): fp32 QKV + the bf16 three-term attention
+        static const bool att_x3 = getenv("RR_CE_H2_ATT_X3") != nullptr;
+        const bool cls_tail = l == ce->cfg.n_layers - 1 && mode != RR_CE_OUT_HIDDEN;
+        if (att_x3) {
+            ce_h2_gemm(CE_H2_EPI_F32, L.wqkv_h2, 3 * CE_H, ce->hx, xs, T, CE_H, L.bqkv, ce->qkv32, nullptr, 0, ce->d_flag, st);
+        } else {
+            ce_h2_gemm(CE_H2_EPI_H2, L.wqkv_h2, 3 * CE_H, ce->hx, xs, T, CE_H, L.bqkv, nullptr, ce->qkv32, xs, ce->d_flag, st,
+                       0.17677669529663687f * 1.4426950408889634f, CE_H);
+            ce_h2_attention(ce->qkv32, xs, d_cu_seqlens, n_seqs, max_len, cls_tail ? ce->ctxhc : ce->ctxh, cls_tail ? xc : xs, ce->d_flag,
+                            cls_tail ? 1 : 0, st);
+        }
+        if (cls_tail) {
             // The last layer of a [CLS]-pooled output needs keys and values of every token but only the [CLS] query row (as
             // the bf16 path below): attention for that row alone, everything behind it on one compact row per sequence.
-            hipLaunchKernelGGL(ce_attention_x3<true>, dim3((unsigned)n_seqs, CE_HEADS), dim3(512), CE_X3A_LDS, st, ce->qkv32, d_cu_seqlens,
-                               (float*)nullptr, 0.17677669529663687f, (u32x2*)ce->ctxhc, xc, ce->d_flag, 1);
+            if (att_x3)
+                hipLaunchKernelGGL(ce_attention_x3<true>, dim3((unsigned)n_seqs, CE_HEADS), dim3(512), CE_X3A_LDS, st, ce->qkv32, d_cu_seqlens,
+                                   (float*)nullptr, 0.17677669529663687f, (u32x2*)ce->ctxhc, xc, ce->d_flag, 1);
             hipLaunchKernelGGL(ce_gather_cls, dim3((unsigned)n_seqs), dim3(128), 0, st, ce->h32, d_cu_seqlens, ce->h32c32);
             ce_h2_gemm(CE_H2_EPI_F32, L.wo_h2, CE_H, ce->ctxhc, xc, n_seqs, CE_H, L.bo, ce->y32c, nullptr, 0, ce->d_flag, st);
             ce_h2_add_ln(ce->y32c, ce->h32c32, n_seqs, L.ln1_g, L.ln1_b, ce->cfg.ln_eps, ce->hxc, xc, ce->d_flag, st);
@@ -1990,11 +2007,12 @@ static int ce_forward_h2(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d
             ce_h2_gemm(CE_H2_EPI_F32, L.w2_h2, CE_H, ce->interhc, xc, n_seqs, CE_FFN, L.b2, ce->y32c, nullptr, 0, ce->d_flag, st);
             ce_h2_add_ln(ce->y32c, ce->h32c32, n_seqs, L.ln2_g, L.ln2_b, ce->cfg.ln_eps, ce->hxc, xc, ce->d_flag, st);
             hipLaunchKernelGGL(ce_head, dim3((unsigned)n_seqs), dim3(256), 0, st, ce->h32c32, (const int32_t*)nullptr, ce->wp, ce->bp, ce->wc,
-                               ce->bc, ce->cfg.n_labels, mode, d_out);
+                               ce->bc, ce->cfg.n_labels, mode, d_out, (const unsigned*)ce->d_flag);
             return RR_OK;
         }
-        hipLaunchKernelGGL(ce_attention_x3<true>, dim3((unsigned)n_seqs, CE_HEADS), dim3(512), CE_X3A_LDS, st, ce->qkv32, d_cu_seqlens,
-                           (float*)nullptr, 0.17677669529663687f /* 1 / sqrt(32) */, (u32x2*)ce->ctxh, xs, ce->d_flag, 0);
+        if (att_x3)
+            hipLaunchKernelGGL(ce_attention_x3<true>, dim3((unsigned)n_seqs, CE_HEADS), dim3(512), CE_X3A_LDS, st, ce->qkv32, d_cu_seqlens,
+                               (float*)nullptr, 0.17677669529663687f /* 1 / sqrt(32) */, (u32x2*)ce->ctxh, xs, ce->d_flag, 0);
         ce_h2_gemm(CE_H2_EPI_F32, L.wo_h2, CE_H, ce->ctxh, xs, T, CE_H, L.bo, ce->y32, nullptr, 0, ce->d_flag, st);
         ce_h2_add_ln(ce->y32, ce->h32, T, L.ln1_g, L.ln1_b, ce->cfg.ln_eps, ce->hx, xs, ce->d_flag, st);
         ce_h2_gemm(CE_H2_EPI_GELU_H2, L.w1_h2, CE_FFN, ce->hx, xs, T, CE_H, L.b1, nullptr, ce->inter32, xs, ce->d_flag, st);
@@ -2003,7 +2021,6 @@ static int ce_forward_h2(rr_ce* ce, const int32_t* d_token_ids, const int32_t* d
     }
     // (mode != RR_CE_OUT_HIDDEN left through the last layer's [CLS] tail above)
     RR_HIP_TRY(hipMemcpyAsync(d_out, ce->h32, sizeof(float) * (size_t)T * CE_H, hipMemcpyDeviceToDevice, st));
-    (void)max_len;
     return RR_OK;
 }
 
@@ -2012,6 +2029,7 @@ static int ce_forward_f32(rr_ce* ce, const int32_t* d_token_ids, const int32_t* 
     int rc = ce_reserve_f32(ce, T);
     if (rc) return rc;
     // RR_CE_F32_SPLIT=bf16x3 (A/B) or rr_ce_set_wide_range: three bf16 terms per operand, six products -- any fp32 range
+    RR_HIP_TRY(hipMemsetAsync(ce->d_flag, 0, 4, st));
     static const bool split_bf16 = getenv("RR_CE_F32_SPLIT") != nullptr && strcmp(getenv("RR_CE_F32_SPLIT"), "bf16x3") == 0;
     if (!split_bf16 && !ce->wide_range && getenv("RR_CE_F32_MFMA") == nullptr && getenv("RR_CE_F32_ATT_MFMA32") == nullptr)
         return ce_forward_h2(ce, d_token_ids, d_type_ids, d_pos_ids, d_cu_seqlens, n_seqs, T, max_len, mode, d_out, st);
@@ -2049,7 +2067,7 @@ static int ce_forward_f32(rr_ce* ce, const int32_t* d_token_ids, const int32_t* 
         RR_HIP_TRY(hipMemcpyAsync(d_out, ce->h32, sizeof(float) * (size_t)T * CE_H, hipMemcpyDeviceToDevice, st));
     else
         hipLaunchKernelGGL(ce_head, dim3((unsigned)n_seqs), dim3(256), 0, st, ce->h32, d_cu_seqlens, ce->wp, ce->bp, ce->wc, ce->bc,
-                           ce->cfg.n_labels, mode, d_out);
+                           ce->cfg.n_labels, mode, d_out, (const unsigned*)nullptr);
     return RR_OK;
 }
 
@@ -2173,7 +2191,7 @@ extern "C" int rr_ce_forward_dev(rr_ce* ce, const int32_t* d_token_ids, const in
         RR_HIP_TRY(hipMemcpyAsync(d_out, ce->h32, sizeof(float) * (size_t)T * CE_H, hipMemcpyDeviceToDevice, st));
     else
         hipLaunchKernelGGL(ce_head, dim3((unsigned)n_seqs), dim3(256), 0, st, ce->h32c, (const int32_t*)nullptr, ce->wp, ce->bp, ce->wc, ce->bc,
-                           ce->cfg.n_labels, mode, d_out);
+                           ce->cfg.n_labels, mode, d_out, (const unsigned*)nullptr);
     hipEventRecord(ce->ev1, st);
     ce->timed = true;
     RR_HIP_TRY(hipGetLastError());
@@ -2187,6 +2205,26 @@ extern "C" int rr_ce_last_forward_ms(rr_ce* ce, float* out_ms) {
     RR_HIP_TRY(hipSetDevice(ce->device));
     RR_HIP_TRY(hipEventSynchronize(ce->ev1));
     RR_HIP_TRY(hipEventElapsedTime(out_ms, ce->ev0, ce->ev1));
+    return RR_OK;
+}
+
+extern "C" int rr_ce_range_status(rr_ce* ce, int32_t* out_of_range) {
+    RR_REQUIRE(ce && out_of_range, "rr_ce_range_status: NULL argument");
+    std::lock_guard<std::mutex> lk(ce->mu);
+    *out_of_range = 0;
+    if (!ce->timed) return RR_OK;
+    RR_HIP_TRY(hipSetDevice(ce->device));
+    RR_HIP_TRY(hipEventSynchronize(ce->ev1));
+    unsigned f = 0;
+    RR_HIP_TRY(hipMemcpy(&f, ce->d_flag, 4, hipMemcpyDeviceToHost));
+    *out_of_range = f ? 1 : 0;
+    return RR_OK;
+}
+
+extern "C" int rr_ce_set_wide_range(rr_ce* ce, int32_t on) {
+    RR_REQUIRE(ce, "rr_ce_set_wide_range: NULL handle");
+    std::lock_guard<std::mutex> lk(ce->mu);
+    ce->wide_range = on != 0;
     return RR_OK;
 }
 

@@ -12,16 +12,21 @@
 
 #define CE_H2_EPI_F32 0        // out32[token][N] = x W^T + b                         (fp32, row-major)
 #define CE_H2_EPI_H2 1         // out2 = h2(x W^T + b)
-#define CE_H2_EPI_GELU_H2 2    // out2 = h2(gelu_erf(x W^T + b))
-#define CE_H2_EPI_VT 3         // out2 = the V^T image ce_h2_attention reads (see rr_ce_h2.hip)
+#define CE_H2_EPI_GELU_H2 2    // out2 = h2(gelu(x W^T + b)), gelu = x Phi(x) (the erf form)
 
 // rows [R][K] fp32 row-major (device) -> h2 planes
 void ce_h2_pack(const float* d_src, int R, int K, void* d_dst, int64_t row_stride, hipStream_t st);
 // out = X W^T + bias, X: h2 [M tokens][K] (row stride xs), W: h2 [N][K] (row stride N); N % 128 == 0, K % 32 == 0.
 // out32 (EPI_F32) has leading dimension N; out2 (the other epilogues) has N / 8 chunks and row stride `os`.
-// *flag is OR-ed with 1 if a value that is split to fp16 falls outside its range (|v| > 65504).
+// *flag is OR-ed with 1 if a value that is split to fp16 falls outside its range (|v| > 65504).  CE_H2_EPI_H2 multiplies
+// the features below `qcols` by `qscale` (the attention's 1 / sqrt(d) log2 e, folded into the query projection).
 void ce_h2_gemm(int epi, const void* W2, int N, const void* X2, int64_t xs, int M, int K, const float* bias, float* out32,
-                void* out2, int64_t os, unsigned* flag, hipStream_t st);
+                void* out2, int64_t os, unsigned* flag, hipStream_t st, float qscale = 1.f, int qcols = 0);
+// softmax(Q K^T / sqrt(32)) V per (sequence, head): qkv = ONE h2 image of [T][1152] (Q columns pre-scaled by
+// 1 / sqrt(32) * log2 e, then K, then V; row stride xs), ctx2 = the context as an h2 image (row stride os).
+// cls_only: only query 0 of every sequence, written to row `sequence` of ctx2.
+void ce_h2_attention(const void* qkv, int64_t xs, const int32_t* cu, int n_seqs, int max_len, void* ctx2, int64_t os, unsigned* flag,
+                     int cls_only, hipStream_t st);
 int ce_h2_set_attributes();
 // word + position + type embeddings -> LayerNorm -> h32 (fp32 rows) + hx (h2, row stride xs)
 void ce_h2_embed_ln(const int32_t* tok, const int32_t* typ, const int32_t* pos, int T, int vocab, int n_pos, int n_typ,

@@ -44,6 +44,16 @@ __device__ __forceinline__ bool h2_out_of_range(float x) { return !(__builtin_fa
 __device__ __forceinline__ void h2_raise(bool bad, unsigned* flag) {
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
+__device__ __forceinline__ float h2_vmax(float a, float b) {      // (no canonicalising v_max x, x in front: the inputs are MFMA sums)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float h2_vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ float h2_wave_sum(float v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
@@ -180,8 +190,7 @@ void ce_h2_add_ln(const float* y, float* h32, int T, const float* g, const float
 // Workgroup = 8 waves, tile = 128 features x 256 tokens, wave (wf = w & 1, wt = w >> 1) = 64 features x 64 tokens = 4 x 4
 // MFMA tiles, two accumulators (128 registers); two waves per SIMD, one workgroup per CU.  The MFMA computes the TRANSPOSED
 // tile, D[feature][token] = W X^T (A operand = the weights): a lane then holds four consecutive FEATURES of one token --
-// 16 bytes of an fp32 row, or the 8-byte half of an h2 unit.  (CE_H2_EPI_VT swaps the operands, D[token][feature]: four
-// consecutive tokens of one feature, what the V^T image wants.)
+// 16 bytes of an fp32 row, or the 8-byte half of an h2 unit.
 // K step = 32 = one MFMA depth; per step a stage of LDS holds W [plane][chunk][128 rows] (16 KB) and X [plane][chunk][256 rows]
 // (32 KB) in units: 48 LDS-DMA pieces of 64 rows, six per wave.  Three stages: the pieces of step s + 2 are issued right
 // after the barrier of step s (every wave has read stage s - 1 by then), `s_waitcnt vmcnt(6)` + the barrier make stage s
@@ -197,14 +206,31 @@ void ce_h2_add_ln(const float* y, float* h32, int T, const float* g, const float
 
 #define H2_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 
-__device__ __forceinline__ float h2_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// gelu(x) = x Phi(x) = max(x, 0) - |x| / 2 * erfc(|x| / sqrt 2), erfc(t) = 2^(t P(t)) with P of degree 7 (tools/fit_gelu_f32.py:
+// weighted minimax fit on [0, 4.25], the argument clamped there -- erfc(4.25) = 1.8e-9): no branch, one v_exp_f32, 13 vector
+// operations against ~40 for the library's erff, which made the FFN's first GEMM vector-bound.  In fp32 with this operation
+// order: |error| <= 2.5e-7 (8.9e-8 of max(1, |x|)) against the float64 value, where torch's own fp32 gelu sits at 1.2e-6.
+__device__ __forceinline__ float h2_gelu(float x) {
+    const float a = __builtin_fabsf(x);
+    const float t = __builtin_fminf(a * 0.70710678118654752440f, 4.25f);
+    float p = -3.043266588e-05f;
+    p = __builtin_fmaf(p, t, 3.174242738e-04f);
+    p = __builtin_fmaf(p, t, -1.051770989e-03f);
+    p = __builtin_fmaf(p, t, -1.539122313e-03f);
+    p = __builtin_fmaf(p, t, 2.898171730e-02f);
+    p = __builtin_fmaf(p, t, -1.488533765e-01f);
+    p = __builtin_fmaf(p, t, -9.183242917e-01f);
+    p = __builtin_fmaf(p, t, -1.627916813e+00f);
+    const float e = __builtin_amdgcn_exp2f(p * t);
+    return __builtin_fmaf(-0.5f * a, e, __builtin_fmaxf(x, 0.f));
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict__ W2, int N, const h2_u32x4* __restrict__ X2, int64_t xs,
                                                      int M, int K, const float* __restrict__ bias, float* __restrict__ out32,
-                                                     h2_u32x2* __restrict__ out2, int64_t os, unsigned* __restrict__ flag) {
+                                                     h2_u32x2* __restrict__ out2, int64_t os, unsigned* __restrict__ flag, float qscale,
+                                                     int qcols) {
     extern __shared__ __attribute__((aligned(16))) h2_u32x4 h2g_lds[];
-    constexpr bool SWAP = EPI == CE_H2_EPI_VT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nf = N / H2G_BF;
@@ -268,9 +294,7 @@ __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict_
         H2_READ(xl[0], bX, 16384); H2_READ(xl[1], bX, 16384 + 256); H2_READ(xl[2], bX, 16384 + 512); H2_READ(xl[3], bX, 16384 + 768);
         H2_READ(wl[0], bW, 8192); H2_READ(wl[1], bW, 8192 + 256); H2_READ(wl[2], bW, 8192 + 512); H2_READ(wl[3], bW, 8192 + 768);
         asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(wh[0]), "+v"(wh[1]), "+v"(wh[2]), "+v"(wh[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]) :: "memory");
-#define H2_MFMA(A, B, C) \
-    C = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h2_f16x8, B), __builtin_bit_cast(h2_f16x8, A), C, 0, 0, 0) \
-             : __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h2_f16x8, A), __builtin_bit_cast(h2_f16x8, B), C, 0, 0, 0)
+#define H2_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h2_f16x8, A), __builtin_bit_cast(h2_f16x8, B), C, 0, 0, 0)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -290,7 +314,7 @@ __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict_
 
     // ---- epilogue
     bool bad = false;
-    if (!SWAP) {
+    {
         // acc[i][j][e]: feature n0 + 64 wf + 16 i + 4 kq + e, token m0 + 64 wt + 16 j + r
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -303,7 +327,8 @@ __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = __builtin_fmaf(acc2[i][j][e], CE_H2_INV_SCALE, acc1[i][j][e]) + bv[e];
-                    if (EPI == CE_H2_EPI_GELU_H2) v[e] = h2_gelu_erf(v[e]);
+                    if (EPI == CE_H2_EPI_GELU_H2) v[e] = h2_gelu(v[e]);
+                    if (EPI == CE_H2_EPI_H2 && f < qcols) v[e] *= qscale;
                 }
                 if (t >= M) continue;
                 if (EPI == CE_H2_EPI_F32) {
@@ -323,58 +348,262 @@ __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict_
                 }
             }
         }
-    } else {
-        // acc[i][j][e]: token m0 + 64 wt + 16 j + 4 kq + e, feature (= dim) n0 + 64 wf + 16 i + r.  V^T image: unit
-        // (plane, 32-token group g, dim, q) at ((plane * G + g) * N + dim) * 4 + q, G = os / 32, holds the EIGHT k slots
-        // 8 q + 4 a + e  <->  token 32 g + 16 a + 4 q + e (a = 0, 1): the order ce_attention_h2's probabilities sit in.
-        // Tokens past M are written as zeros (their group may be read, with probability 0).
-        const int64_t G = os >> 5;
+    }
+    if (EPI != CE_H2_EPI_F32) h2_raise(bad, flag);
+}
+
+void ce_h2_gemm(int epi, const void* W2, int N, const void* X2, int64_t xs, int M, int K, const float* bias, float* out32,
+                void* out2, int64_t os, unsigned* flag, hipStream_t st, float qscale, int qcols) {
+    const int tbs = (M + H2G_BT - 1) / H2G_BT;
+    const dim3 grid((unsigned)(((tbs + 7) / 8) * 8 * (N / H2G_BF)));
+#define H2_LAUNCH(E) \
+    hipLaunchKernelGGL((ce_gemm_h2<E>), grid, dim3(512), H2G_LDS, st, (const h2_u32x4*)W2, N, (const h2_u32x4*)X2, xs, M, K, bias, out32, \
+                       (h2_u32x2*)out2, os, flag, qscale, qcols)
+    if (epi == CE_H2_EPI_F32) H2_LAUNCH(CE_H2_EPI_F32);
+    else if (epi == CE_H2_EPI_H2) H2_LAUNCH(CE_H2_EPI_H2);
+    else H2_LAUNCH(CE_H2_EPI_GELU_H2);
+#undef H2_LAUNCH
+}
+
+// ------------------------------------------------------------------ attention
+// One workgroup (eight waves) per (sequence, head), the sequence's keys in groups of 32.  Q (scaled by log2 e / sqrt 32 in the
+// projection's epilogue), K and V arrive in ONE h2 image of [T][1152] (chunks 4 head .. + 3 of the Q / K / V thirds): per
+// (plane, chunk) a token is one 16-byte unit.  K and V of every group go to LDS by LDS-DMA at once (8 KB per group, <= 16
+// groups = 128 KB, one workgroup per CU) into the SAME image form, [plane][key][4 slots] with the chunk of key k in slot
+// chunk ^ 2 ((k >> 2) & 1) -- the DMA lays lanes out linearly in LDS, so the swizzle is applied to the global address a lane
+// fetches.  That one image serves both products (cdna_hip_programming.md T10, "one image for row reads and transposed reads"):
+//   S^T[key][query] = K Q^T on v_mfma_f32_16x16x32_f16 (K = 32 = the head dimension: one MFMA per term and 16 x 16 tile): the A
+//     operand of lane (key r, chunk kq) is one ds_read_b128, conflict-free under the swizzle;
+//     s = s1 + s2 / 2048, s1 = Khi Qhi, s2 = Khi Qlo + Klo Qhi;
+//   online softmax in base 2; a lane holds the 8 scores of ITS query against keys 16 a + 4 (l >> 4) + e (a = 0, 1), the row
+//     maximum is two v_permlane swaps away; p = 2^(s - m + 15) -- the 2^15 keeps a probability down to 2e-9 a normal fp16 (below,
+//     the matrix core reads 0: <= 2e-9 per key, against fp32's own 6e-8 on the largest); it cancels in o / l;
+//   O^T[dim][query] += V^T P^T: the lane's 8 probabilities ARE the B operand's k slots 8 (l >> 4) + 4 a + e, so P never leaves
+//     its registers, and the A operand -- dim (l & 15) against exactly those keys -- is two ds_read_b64_tr_b16 of the row-major
+//     V image (the hardware transpose: 4 keys x 16 dims per 16 lanes), conflict-free under the same swizzle;
+//     o1 += Vhi Phi, o2 += Vhi Plo + Vlo Phi.
+// The context leaves as an h2 image: a lane holds four consecutive dims of its query = one 8-byte half unit.  Nothing depends on
+// where the sequence sits in the pack: a sequence's scores are bit for bit the same alone or in any batch.
+#define H2A_GROUP_UNITS 512
+#define H2A_MAX_GROUPS 16
+#define H2A_LDS (H2A_MAX_GROUPS * H2A_GROUP_UNITS * 16)
+#define H2A_CHUNKS 144                                          // 16-byte units per token and plane: 1152 / 8
+typedef __fp16 h2_tr4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+typedef float h2_f32x2 __attribute__((ext_vector_type(2)));
+
+// NT query tiles of one wave (tiles qt0, qt0 + 8, ...) against every key group, their chains interleaved in one instruction
+// stream: a tile's chain is MFMA -> vector -> MFMA, each step waiting for the one before; with one tile per pass the wave
+// spent most of its time waiting (measured: 650 us per layer at 131 072 tokens with one tile, the K / V fragments are read
+// once for the NT tiles besides).
+template <int NT>
+__device__ __forceinline__ void h2a_tiles(const h2_u32x4* __restrict__ qkv, int64_t xs, int t0, int S, int ng, int head, int qt0, int n_tiles,
+                                          const h2_u32x4* kimg, const char* vimg, int vdi, int r, int kq, h2_u32x2* __restrict__ ctx2,
+                                          int64_t os, int64_t cls_row, bool& bad) {
+    h2_f16x8 bqh[NT], bql[NT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int d = n0 + 64 * wf + 16 * i + r;
-            const float bv = bias[d];
+    for (int t = 0; t < NT; ++t) {
+        int q = 16 * (qt0 + 8 * t) + r;
+        q = q < S ? q : S - 1;                            // (lanes / tiles past the sequence: a valid row, never stored)
+        const h2_u32x4* p = qkv + ((int64_t)(head * 4 + kq) * xs + t0 + q);
+        bqh[t] = __builtin_bit_cast(h2_f16x8, p[0]);
+        bql[t] = __builtin_bit_cast(h2_f16x8, p[H2A_CHUNKS * xs]);
+    }
+    h2_f32x4 o1[NT][2], o2[NT][2];
+    float mm[NT];                                          // running maximum - 15
+    h2_f32x2 lsum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            o1[t][i] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
+            o2[t][i] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        mm[t] = -INFINITY;
+        lsum[t] = h2_f32x2{0.f, 0.f};
+    }
+    for (int gi = 0; gi < ng; ++gi) {
+        const h2_u32x4* kb = kimg + gi * H2A_GROUP_UNITS;
+        h2_f16x8 kh[2], kl[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            kh[a] = __builtin_bit_cast(h2_f16x8, kb[64 * a]);
+            kl[a] = __builtin_bit_cast(h2_f16x8, kb[128 + 64 * a]);
+        }
+        h2_f32x2 s[NT][4];                                 // [a][e pair]: keys 16 a + 4 kq + 2 j, + 1
+        float cm[NT];
+        const bool last = 32 * gi + 32 > S;                // (wave-uniform) the sequence's last group holds padding keys
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const h2_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const h2_f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[a], bqh[t], z, 0, 0, 0);
+                h2_f32x4 s2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[a], bql[t], z, 0, 0, 0);
+                s2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[a], bqh[t], s2, 0, 0, 0);
+                const h2_f32x2 c = {CE_H2_INV_SCALE, CE_H2_INV_SCALE};
+                s[t][2 * a] = __builtin_elementwise_fma(h2_f32x2{s2[0], s2[1]}, c, h2_f32x2{s1[0], s1[1]});
+                s[t][2 * a + 1] = __builtin_elementwise_fma(h2_f32x2{s2[2], s2[3]}, c, h2_f32x2{s1[2], s1[3]});
+            }
+            if (last) {
+                const int key0 = 32 * gi + 4 * kq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int key = key0 + 16 * (j >> 1) + 2 * (j & 1);
+                    s[t][j][0] = key < S ? s[t][j][0] : -INFINITY;
+                    s[t][j][1] = key + 1 < S ? s[t][j][1] : -INFINITY;
+                }
+            }
+            float m8 = h2_vmax3(h2_vmax3(s[t][0][0], s[t][0][1], s[t][1][0]), h2_vmax3(s[t][1][1], s[t][2][0], s[t][2][1]), h2_vmax(s[t][3][0], s[t][3][1]));
+            const auto x16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(m8), __float_as_uint(m8), false, false);
+            m8 = h2_vmax(__uint_as_float(x16[0]), __uint_as_float(x16[1]));
+            const auto x32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m8), __float_as_uint(m8), false, false);
+            cm[t] = h2_vmax(__uint_as_float(x32[0]), __uint_as_float(x32[1])) - 15.f;
+        }
+        bool grow = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) grow |= cm[t] > mm[t];
+        if (__any(grow)) {                                 // (wave-uniform; after the first groups a new maximum is rare)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float nm = h2_vmax(mm[t], cm[t]);
+                const float f = __builtin_amdgcn_exp2f(mm[t] - nm);      // first group: 2^-inf = 0; no change: 1
+                lsum[t] *= f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    o1[t][i] *= f;
+                    o2[t][i] *= f;
+                }
+                mm[t] = nm;
+            }
+        }
+        h2_f16x8 ph[NT], pl[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const h2_f32x2 m2 = {mm[t], mm[t]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int tq = m0 + 64 * wt + 16 * j + 4 * kq;
+                const h2_f32x2 d = s[t][j] - m2;
+                const h2_f32x2 pe = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};      // masked keys: 2^-inf = 0
+                lsum[t] += pe;
+                const _Float16 h0 = (_Float16)pe[0], h1 = (_Float16)pe[1];
+                ph[t][2 * j] = h0;
+                ph[t][2 * j + 1] = h1;
+                const h2_f32x2 rr = (pe - h2_f32x2{(float)h0, (float)h1}) * h2_f32x2{CE_H2_SCALE, CE_H2_SCALE};
+                pl[t][2 * j] = (_Float16)rr[0];
+                pl[t][2 * j + 1] = (_Float16)rr[1];
+            }
+        }
+        const char* vb = vimg + gi * (H2A_GROUP_UNITS * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* vi = vb + i * vdi;
+            h2_tr4 tr[2][2];
+#pragma unroll
+            for (int pln = 0; pln < 2; ++pln)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    tr[pln][a] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h2_tr4*)(vi + pln * 2048 + a * 1024));
+            h2_f16x8 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vh[e] = (_Float16)tr[0][0][e]; vh[4 + e] = (_Float16)tr[0][1][e];
+                vl[e] = (_Float16)tr[1][0][e]; vl[4 + e] = (_Float16)tr[1][1][e];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                o1[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[t], o1[t][i], 0, 0, 0);
+                o2[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[t], o2[t][i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o2[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t], o2[t][i], 0, 0, 0);
+        }
+    }
+    // ---- the row sum over the query's four lanes, normalise, split, store: o[i][e] = dim 16 i + 4 kq + e of query 16 qt + r
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float l = lsum[t][0] + lsum[t][1];
+        const auto x16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+        l = __uint_as_float(x16[0]) + __uint_as_float(x16[1]);
+        const auto x32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
+        l = __uint_as_float(x32[0]) + __uint_as_float(x32[1]);
+        const int qt = qt0 + 8 * t, q = 16 * qt + r;
+        if (qt < n_tiles && q < S && (cls_row < 0 || q == 0)) {
+            const float inv = 1.0f / l;
+            const int64_t row = cls_row >= 0 ? cls_row : t0 + q;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
                 h2_f16x4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = __builtin_fmaf(acc2[i][j][e], CE_H2_INV_SCALE, acc1[i][j][e]) + bv;
-                    v = tq + e < M ? v : 0.f;
-                    const h2_pair p = h2_split(v);
-                    hi[e] = p.hi;
-                    lo[e] = p.lo;
+                    const float v = __builtin_fmaf(o2[t][i][e], CE_H2_INV_SCALE, o1[t][i][e]) * inv;
+                    const h2_pair pr = h2_split(v);
+                    hi[e] = pr.hi;
+                    lo[e] = pr.lo;
                     bad |= h2_out_of_range(v);
                 }
-                const int64_t g = tq >> 5;
-                const int a = (tq >> 4) & 1;
-                const int64_t u = ((g * N + d) << 2) + kq;
-                out2[2 * u + a] = __builtin_bit_cast(h2_u32x2, hi);
-                out2[2 * ((G * N << 2) + u) + a] = __builtin_bit_cast(h2_u32x2, lo);
+                const int64_t u = (int64_t)(head * 4 + 2 * i + (kq >> 1)) * os + row;
+                ctx2[2 * u + (kq & 1)] = __builtin_bit_cast(h2_u32x2, hi);
+                ctx2[2 * ((int64_t)(H2_H / 8) * os + u) + (kq & 1)] = __builtin_bit_cast(h2_u32x2, lo);
             }
         }
     }
-    if (EPI != CE_H2_EPI_F32) h2_raise(bad, flag);
+}
+
+__global__ __launch_bounds__(512, 1) void ce_attention_h2(const h2_u32x4* __restrict__ qkv, int64_t xs, const int32_t* __restrict__ cu,
+                                                          h2_u32x2* __restrict__ ctx2, int64_t os, unsigned* __restrict__ flag,
+                                                          int cls_only) {
+    extern __shared__ __attribute__((aligned(16))) h2_u32x4 h2a_lds[];
+    const int seq = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    const int ng = (S + 31) >> 5;
+    // ---- staging: wave w = (K | V: w >> 2, plane (w >> 1) & 1, key half w & 1) of every group; lane = (key, slot)
+    {
+        const int which = w >> 2, p = (w >> 1) & 1, key = 16 * (w & 1) + (lane >> 2), slot = lane & 3;
+        const int chunk = slot ^ (2 * ((key >> 2) & 1));
+        const h2_u32x4* plane = qkv + (int64_t)(p * H2A_CHUNKS + 48 * (1 + which) + head * 4 + chunk) * xs;
+        const int dst = which * 256 + p * 128 + 64 * (w & 1);
+        for (int gi = 0; gi < ng; ++gi) {
+            int k = 32 * gi + key;
+            k = k < S ? k : S - 1;                         // (keys past the sequence: a valid row; masked / probability 0)
+            __builtin_amdgcn_global_load_lds(plane + t0 + k, (__attribute__((address_space(3))) void*)(h2a_lds + gi * H2A_GROUP_UNITS + dst), 16, 0, 0);
+        }
+    }
+    const int r = lane & 15, kq = lane >> 4;
+    const int n_tiles = cls_only ? 1 : (S + 15) >> 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // K row reads: lane (key 16 a + r, chunk kq): unit plane * 128 + key * 4 + (kq ^ 2 ((r >> 2) & 1))
+    const h2_u32x4* kimg = h2a_lds + r * 4 + (kq ^ (2 * ((r >> 2) & 1)));
+    // V transposed reads: lane (q = (l >> 2) & 3, pp = l & 3) of group kq addresses key 16 a + 4 kq + q, dims 16 i + 4 pp .. + 3:
+    // chunk 2 i + (pp >> 1) in slot chunk ^ 2 (kq & 1), byte half pp & 1
+    const int vq = (lane >> 2) & 3, vpp = lane & 3;
+    const char* vimg = (const char*)(h2a_lds + 256 + (4 * kq + vq) * 4 + ((vpp >> 1) ^ (2 * (kq & 1)))) + 8 * (vpp & 1);
+    const int vdi = ((vpp >> 1) ^ (2 * (kq & 1))) & 2 ? -32 : 32;      // dims 16 .. 31: chunk + 2 = slot ^ 2 = 32 bytes up or down
+    bool bad = false;
+    const int64_t cls_row = cls_only ? seq : -1;
+    if (w < n_tiles) {                                     // (wave-uniform; every lane of the wave runs the transposed reads)
+        if (n_tiles > 16) h2a_tiles<4>(qkv, xs, t0, S, ng, head, w, n_tiles, kimg, vimg, vdi, r, kq, ctx2, os, cls_row, bad);
+        else if (n_tiles > 8) h2a_tiles<2>(qkv, xs, t0, S, ng, head, w, n_tiles, kimg, vimg, vdi, r, kq, ctx2, os, cls_row, bad);
+        else h2a_tiles<1>(qkv, xs, t0, S, ng, head, w, n_tiles, kimg, vimg, vdi, r, kq, ctx2, os, cls_row, bad);
+    }
+    if (bad) atomicOr(flag, 1u);
+}
+
+void ce_h2_attention(const void* qkv, int64_t xs, const int32_t* cu, int n_seqs, int max_len, void* ctx2, int64_t os, unsigned* flag,
+                     int cls_only, hipStream_t st) {
+    const int groups = (max_len + 31) / 32;
+    const size_t lds = (size_t)(groups < H2A_MAX_GROUPS ? groups : H2A_MAX_GROUPS) * H2A_GROUP_UNITS * 16;
+    hipLaunchKernelGGL(ce_attention_h2, dim3((unsigned)n_seqs, 12), dim3(512), lds, st, (const h2_u32x4*)qkv, xs, cu, (h2_u32x2*)ctx2, os, flag,
+                       cls_only);
 }
 
 int ce_h2_set_attributes() {
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_H2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_GELU_H2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_VT>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2A_LDS));
     return RR_OK;
 }
 
-void ce_h2_gemm(int epi, const void* W2, int N, const void* X2, int64_t xs, int M, int K, const float* bias, float* out32,
-                void* out2, int64_t os, unsigned* flag, hipStream_t st) {
-    const int tbs = (M + H2G_BT - 1) / H2G_BT;
-    const dim3 grid((unsigned)(((tbs + 7) / 8) * 8 * (N / H2G_BF)));
-#define H2_LAUNCH(E) \
-    hipLaunchKernelGGL((ce_gemm_h2<E>), grid, dim3(512), H2G_LDS, st, (const h2_u32x4*)W2, N, (const h2_u32x4*)X2, xs, M, K, bias, out32, \
-                       (h2_u32x2*)out2, os, flag)
-    if (epi == CE_H2_EPI_F32) H2_LAUNCH(CE_H2_EPI_F32);
-    else if (epi == CE_H2_EPI_H2) H2_LAUNCH(CE_H2_EPI_H2);
-    else if (epi == CE_H2_EPI_GELU_H2) H2_LAUNCH(CE_H2_EPI_GELU_H2);
-    else H2_LAUNCH(CE_H2_EPI_VT);
-#undef H2_LAUNCH
-}

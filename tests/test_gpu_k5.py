@@ -348,3 +348,46 @@ def test_fp32_mode_on_the_fp32_input_matrix_instruction_meets_the_same_bar(ce_wo
     got = np.array([float(v) for v in [l for l in p.stdout.splitlines() if l.startswith("LOGITS ")][-1].split()[1:]], dtype=np.float32)
     assert np.abs(got - fx["logits"]).max() < F32_LOGIT_TOL
     assert np.abs(got - ce.predict_ids(split(fx))).max() < F32_LOGIT_TOL
+
+
+def test_fp32_mode_two_splits_agree_and_a_value_beyond_fp16_switches_the_handle(ce_world_f32):
+    """RR_CE_PRECISION_F32 multiplies fp16 pairs (hi + lo / 2048: three MFMA products, csrc/rr_ce_h2.hip); the bf16 three-term
+    kernels (six products, any fp32 range) stay behind `set_wide_range`.  (1) On the seeded model the two agree to fp32
+    rounding on logits and hidden states.  (2) A model whose FFN output exceeds 65504 cannot be split into fp16: the
+    device raises its flag, the logits of that pass are NaN -- never a wrong finite number --, `forward_ids` notices,
+    switches the handle and returns what a wide-range handle returns, bit for bit."""
+    fx, sd, ce = ce_world_f32
+    seqs = split(fx)[:12]
+    wide = CrossEncoder(sd)
+    wide.model.set_wide_range(True)
+    a, b = ce.predict_ids(seqs), wide.predict_ids(seqs)
+    assert not ce.model.out_of_range() and not wide.model.out_of_range()
+    print("fp16-pair vs bf16-triple logits: max |diff|", np.abs(a - b).max())
+    assert np.abs(a - b).max() < 4e-6
+    ha, hb = ce.model.forward_ids(seqs, OUT_HIDDEN), wide.model.forward_ids(seqs, OUT_HIDDEN)
+    assert np.abs(ha - hb).max() < 2e-5
+    # (2) blow one layer's FFN up: |intermediate| reaches ~1e5
+    big = dict(sd)
+    key = [k for k in big if k.endswith("encoder.layer.2.intermediate.dense.weight")][0]
+    big[key] = np.asarray(big[key], dtype=np.float32) * np.float32(4.0e4)
+    ref = CrossEncoder(big)
+    ref.model.set_wide_range(True)
+    want = ref.predict_ids(seqs)
+    assert np.isfinite(want).all()
+    auto = CrossEncoder(big)
+    ids = np.concatenate([np.asarray(s[0], dtype=np.int32) for s in seqs])
+    import torch
+    lens = np.array([len(s[0]) for s in seqs])
+    cu = np.zeros(len(seqs) + 1, dtype=np.int32)
+    np.cumsum(lens, out=cu[1:])
+    dev = torch.device("cuda", 0)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).to(dev)
+    pos = (np.arange(cu[-1]) - np.repeat(cu[:-1], lens)).astype(np.int32)
+    typ = np.concatenate([np.asarray(s[1], dtype=np.int32) for s in seqs])
+    raw = auto.model.forward_packed_dev(t(ids), t(typ), t(pos), t(cu), len(seqs), int(lens.max()), 0)
+    torch.cuda.synchronize()
+    assert auto.model.out_of_range() and bool(torch.isnan(raw).all())
+    with pytest.warns(UserWarning, match="fp16 range"):
+        got = auto.predict_ids(seqs)
+    assert np.array_equal(got, want)
+    assert not auto.model.out_of_range()                     # (the handle now runs the wide-range kernels)
