@@ -19,9 +19,9 @@ def main():
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16",
-                    help="bf16 = the fast path (roofline: bf16 MFMA); fp32 = reference precision: fp32 FLOPs of the model against the "
-                         "fp32-input MFMA peak (157 TF/s) -- the yardstick only: its GEMMs run as six bf16 MFMA products per fp32 "
-                         "product (RR_CE_F32_MFMA=1 puts them on the fp32-input instruction)")
+                    help="bf16 = the fast path (roofline: bf16 MFMA); fp32 = reference precision: every fp32 product as three fp16 MFMA "
+                         "products (roofline: 3 x the executed FLOPs against the fp16 MFMA peak; RR_CE_F32_SPLIT=bf16x3: six bf16 "
+                         "products, RR_CE_F32_MFMA=1: the fp32-input instruction)")
     a = ap.parse_args()
     from review_recommender_amd import synth
     from review_recommender_amd.cross_encoder import CrossEncoder
@@ -44,24 +44,25 @@ def main():
         ce.predict_ids(seqs)
         ms.append(ce.model.last_forward_ms())
     t = float(np.median(ms)) * 1e-3
-    peak = 2500.0 if a.precision == "bf16" else 157.3
-    if a.precision == "fp32":
-        flops = model_flops                                   # the fp32 mode computes every token of every layer
-    # attention is NOT on the MFMA roof: head dim 32 means one v_exp_f32 (quarter rate) per 64 MACs of QK^T + 64 of PV, and the
-    # fp32 mode adds the three-term split of every probability: its share of the forward is vector-bound.  Stated here so
-    # the whole-forward MFMA fraction below is not read as the attention kernels' own roof.
+    # fp32 precision: every fp32 product is THREE fp16 MFMA products (csrc/rr_ce_h2.hip: operands as hi + lo / 2048), so the
+    # matrix cores execute 3 x the model's FLOPs; the roofline below prices those against the dense fp16 peak (= the bf16 one).
+    terms = 1 if a.precision == "bf16" else 3
+    peak = 2500.0
+    # attention is NOT on the MFMA roof: head dim 32 means one v_exp_f32 (a quarter-rate instruction: 4 lanes per cycle and
+    # SIMD) per 64 MACs of QK^T + 64 of PV, and the fp32 mode adds the two-term split of every probability: its share of the
+    # forward is vector-bound.  Stated here so the whole-forward MFMA fraction below is not read as the attention kernels' own roof.
     att_flops = a.layers * (4.0 * 384 * lens * lens).sum()
-    exps = a.layers * 12 * (lens * lens).sum()
-    bounds = {"gemm_kernels": "mfma (bf16 matrix cores%s)" % ("" if a.precision == "bf16" else ": six bf16 term products per fp32 product"),
-              "attention_kernels": {"bound": "vector (exp): one v_exp_f32 per score, 16 lanes per cycle and SIMD",
+    exps = (a.layers - 1) * 12 * (lens * lens).sum() + 12 * (16 * lens).sum()
+    bounds = {"gemm_kernels": "mfma (%s)" % ("bf16 matrix cores" if a.precision == "bf16" else "fp16 matrix cores: three fp16 term products per fp32 product"),
+              "attention_kernels": {"bound": "vector (exp + probability split): one v_exp_f32 per score at 4 lanes per cycle and SIMD",
                                     "share_of_model_flops": round(att_flops / model_flops, 4),
-                                    "exp_floor_ms_at_2.1GHz": round(exps / (256 * 4 * 16 * 2.1e9) * 1e3, 3)}}
+                                    "exp_floor_ms_at_2.1GHz": round(exps / (256 * 4 * 4 * 2.1e9) * 1e3, 3)}}
     print(json.dumps({"precision": a.precision, "pairs": a.pairs, "tokens": int(T), "layers": a.layers, "forward_ms": round(t * 1e3, 3),
                       "pairs_per_s": round(a.pairs / t, 1), "tokens_per_s": round(T / t, 1),
                       "model_tflop": round(model_flops / 1e12, 4), "executed_tflop": round(flops / 1e12, 4),
-                      "achieved_tflops": round(flops / t / 1e12, 2),
-                      "roofline": {"bound": "mfma", "achieved": round(flops / t / 1e12, 2), "peak": peak,
-                                   "unit": "TFLOP/s", "frac": round(flops / t / (peak * 1e12), 4)},
+                      "achieved_tflops": round(flops / t / 1e12, 2), "mfma_products_per_fp32_product": terms,
+                      "roofline": {"bound": "mfma", "achieved": round(terms * flops / t / 1e12, 2), "peak": peak,
+                                   "unit": "TFLOP/s", "frac": round(terms * flops / t / (peak * 1e12), 4)},
                       "bounds_by_kernel_family": bounds}))
 
 
