@@ -98,6 +98,7 @@ DEBUG_PROTOTYPES = {
     "rr_debug_scan_flt": (C.c_int, [c_vp, c_i32, c_i32, P(c_f32)]),
     "rr_debug_fltq_compare": (C.c_int, [c_vp, P(c_i64)]),
     "rr_debug_ce_ffn_stamps": (C.c_int, [P(C.c_uint64)]),
+    "rr_debug_ce_h2_stamps": (C.c_int, [P(C.c_uint64)]),
 }
 
 _lib = None

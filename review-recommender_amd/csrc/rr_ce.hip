@@ -1621,7 +1621,7 @@ __global__ __launch_bounds__(512, 2) void ce_attention_x3(const float* __restric
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float v = o[t][4 * g + i] * inv;
-                        hi[i] = __builtin_fabsf(v) < 6.103515625e-05f ? (_Float16)0.f : (_Float16)v;      // (h2_split, rr_ce_h2.hip)
+                        hi[i] = (_Float16)v;                                                                 // (h2_split, rr_ce_h2.hip)
                         lo[i] = (_Float16)((v - (float)hi[i]) * CE_H2_SCALE);
                         bad |= !(__builtin_fabsf(v) <= 65504.f);
                     }

@@ -2,7 +2,8 @@
 //
 // The reference runs both encoders in fp32 torch (app/app_product_search.py:250-251, 277-278).  An fp32 product needs 24 x 24
 // significand bits; fp16 carries 11, so x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048) holds 22-23 bits of x
-// (the subtraction is exact; the scale keeps lo a normal fp16 down to |x - hi| = 3e-8), and
+// (the subtraction is exact; the scale keeps lo a normal fp16 down to |x - hi| = 3e-8, and subnormal fp16 values are
+// multiplied as they are), and
 //     x * y  =  hi_x hi_y  +  (hi_x lo_y + lo_x hi_y) / 2048  +  O(2^-22 x y)
 // is three v_mfma_f32_16x16x32_f16 instead of the six bf16 products of ce_gemm_x3 (rr_ce.hip): the first into one fp32
 // accumulator, the two cross terms into a second one that is scaled by 2^-11 once, in the epilogue.  What is dropped (lo lo,
@@ -20,6 +21,9 @@
 #include "rr_ce_h2.h"
 
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 #include "rr_common.h"
 
@@ -28,15 +32,18 @@ typedef _Float16 h2_f16x4 __attribute__((ext_vector_type(4)));
 typedef float h2_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int h2_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int h2_u32x2 __attribute__((ext_vector_type(2)));
+typedef float h2_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2_f16x2 __attribute__((ext_vector_type(2)));
 
 #define H2_H 384
 
 struct h2_pair { _Float16 hi, lo; };
 __device__ __forceinline__ h2_pair h2_split(float x) {
     h2_pair r;
-    // nearest even; a value whose hi would be a SUBNORMAL fp16 (the matrix cores flush those on input) goes to lo whole:
-    // |x| < 2^-14 is x * 2048 < 2^-3, eleven bits of it
-    r.hi = __builtin_fabsf(x) < 6.103515625e-05f ? (_Float16)0.f : (_Float16)x;
+    // nearest even.  No special case below 2^-14: the vector unit and the matrix core both take SUBNORMAL fp16 values as they
+    // are (tools/probes/f16_flush_probe.hip: entries log-uniform in [1e-7, 1e-3], error 1.3e-7 of sum |a b|), so hi + lo / 2048
+    // holds 22 bits there too; sending such a value to lo alone would keep eleven
+    r.hi = (_Float16)x;
     r.lo = (_Float16)((x - (float)r.hi) * CE_H2_SCALE);         // (exact difference; |.| * 2048 <= |x|)
     return r;
 }
@@ -201,8 +208,7 @@ void ce_h2_add_ln(const float* y, float* h32, int T, const float* g, const float
 #define H2G_BT 256
 #define H2G_BF 128
 #define H2G_STAGE_UNITS 3072
-#define H2G_STAGES 3
-#define H2G_LDS (H2G_STAGES * H2G_STAGE_UNITS * 16)
+#define H2G_LDS (3 * H2G_STAGE_UNITS * 16)
 
 #define H2_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 
@@ -224,29 +230,79 @@ __device__ __forceinline__ float h2_gelu(float x) {
     const float e = __builtin_amdgcn_exp2f(p * t);
     return __builtin_fmaf(-0.5f * a, e, __builtin_fmaxf(x, 0.f));
 }
+// two values at a time: the Horner steps, the products and the last step on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32)
+__device__ __forceinline__ h2_f32x2 h2_gelu2(h2_f32x2 x) {
+    const h2_f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+    const h2_f32x2 t = {__builtin_fminf(a[0] * 0.70710678118654752440f, 4.25f), __builtin_fminf(a[1] * 0.70710678118654752440f, 4.25f)};
+#define H2_C2(c) (h2_f32x2{c, c})
+    h2_f32x2 p = H2_C2(-3.043266588e-05f);
+    p = __builtin_elementwise_fma(p, t, H2_C2(3.174242738e-04f));
+    p = __builtin_elementwise_fma(p, t, H2_C2(-1.051770989e-03f));
+    p = __builtin_elementwise_fma(p, t, H2_C2(-1.539122313e-03f));
+    p = __builtin_elementwise_fma(p, t, H2_C2(2.898171730e-02f));
+    p = __builtin_elementwise_fma(p, t, H2_C2(-1.488533765e-01f));
+    p = __builtin_elementwise_fma(p, t, H2_C2(-9.183242917e-01f));
+    p = __builtin_elementwise_fma(p, t, H2_C2(-1.627916813e+00f));
+    const h2_f32x2 q = p * t;
+    const h2_f32x2 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    const h2_f32x2 m = {__builtin_fmaxf(x[0], 0.f), __builtin_fmaxf(x[1], 0.f)};
+    return __builtin_elementwise_fma(a * H2_C2(-0.5f), e, m);
+#undef H2_C2
+}
+// two values -> (hi, lo) pairs, packed conversions (v_cvt_pk_f16_f32)
+__device__ __forceinline__ void h2_split2(h2_f32x2 x, h2_f16x2& hi, h2_f16x2& lo) {
+    hi = __builtin_convertvector(x, h2_f16x2);
+    lo = __builtin_convertvector((x - __builtin_convertvector(hi, h2_f32x2)) * h2_f32x2{CE_H2_SCALE, CE_H2_SCALE}, h2_f16x2);
+}
 
+#ifdef RR_DEBUG_HARNESS
+// tools/k5_h2_stamps.py: phase clocks of waves 0 and 4 of workgroup 2048 of the LAST ce_gemm_h2 launch with K = 384 and
+// N = 1536: [prologue, wait + barrier, data movement, reads until the first MFMA may start, MFMA issue, epilogue, steps,
+// wall clock (100 MHz)] in shader cycles
+__device__ unsigned long long h2_dbg[2][8];
+#define H2_STAMP(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#define H2_DBG(...) __VA_ARGS__
+#else
+#define H2_STAMP(x)
+#define H2_DBG(...)
+#endif
+// Staging: LDS-DMA (global_load_lds_dwordx4), three LDS stages, no registers.  Two other forms were built and measured
+// (profiles/r04_k5_h2_gemm_stamps.txt, tools/k5_h2_stamps.py): global_load_dwordx4 one step ahead + ds_write_b128 with two LDS
+// stages -- 4 - 10 % slower (QKV 445 vs 405 us at 131 072 tokens) --, and 128-token tiles with two workgroups per CU -- 5 - 8 %
+// slower.
+// A step: `s_waitcnt vmcnt(6)` + the barrier make stage s visible (the pieces of stage s + 1 may still fly); every wave issues
+// its sixteen fragment reads; the SIMD's first wave (w < 4) issues its six pieces of stage s + 2 under their latency, the
+// second one behind its MFMAs (RR_CE_H2_NO_STAGGER=1: both up front); 16 MFMAs hi x hi (acc1), 16 hi x lo + 16 lo x hi (acc2).
+// In-kernel clocks (FFN1 shape, 1.5 GHz shader clock): the SIMD's two waves share one matrix pipe, 2 x 48 MFMAs = 1 536 cycles,
+// and a step takes ~2 330 -- 300 - 500 until the first MFMA (eight waves read 128 KB of LDS at once), the pieces' issue
+// 190 - 300, ~150 at the barrier.  The epilogue (GELU + split + stores: ~11 000 cycles of vector work for the SIMD's two
+// waves) runs with the matrix pipe idle: 27 % of an FFN1 tile.  Also built and measured slower: the next stage's high-plane
+// fragments read one step ahead (every stage must then land within ONE step: 13.8 vs 13.1 ms per forward).
 template <int EPI>
-__global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict__ W2, int N, const h2_u32x4* __restrict__ X2, int64_t xs,
-                                                     int M, int K, const float* __restrict__ bias, float* __restrict__ out32,
+__global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict__ W2, int N, const h2_u32x4* __restrict__ X2, int64_t xs, int M,
+                                                     int K, const float* __restrict__ bias, float* __restrict__ out32,
                                                      h2_u32x2* __restrict__ out2, int64_t os, unsigned* __restrict__ flag, float qscale,
-                                                     int qcols) {
+                                                     int qcols, int stagger) {
     extern __shared__ __attribute__((aligned(16))) h2_u32x4 h2g_lds[];
+    constexpr int TB = H2G_BT;
+    constexpr int PW = 6;                                  // 1 KB pieces per wave and stage: 48 / 8
+    constexpr int STAGE_UNITS = H2G_STAGE_UNITS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nf = N / H2G_BF;
     const int id = blockIdx.x, slot = id >> 3;
     const int tb = (slot / nf) * 8 + (id & 7), fb = slot % nf;
-    const int m0 = tb * H2G_BT, n0 = fb * H2G_BF;
+    const int m0 = tb * TB, n0 = fb * H2G_BF;
     if (m0 >= M) return;                                   // (whole workgroup: the grid is padded to eight token blocks)
     const int KC = K >> 3, KS = K >> 5;
 
-    // ---- LDS-DMA pieces of this wave: g = 6 w + j; g < 16: W piece (plane-chunk g >> 1, row half g & 1), else X piece
-    const h2_u32x4* src[6];
-    int64_t step[6];
-    int dst[6];
+    // ---- the pieces of this wave: g = 6 w + j; g < 16: W piece (plane-chunk g >> 1, row half g & 1), else X piece
+    const h2_u32x4* src[PW];
+    int64_t step[PW];
+    int dst[PW];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int g = 6 * w + j;
+    for (int j = 0; j < PW; ++j) {
+        const int g = PW * w + j;
         if (g < 16) {
             const int pc = g >> 1, half = g & 1;
             src[j] = W2 + ((int64_t)((pc >> 2) * KC + (pc & 3)) * N + n0 + 64 * half + lane);
@@ -256,19 +312,20 @@ __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict_
             const int pc = (g - 16) >> 2, q = (g - 16) & 3;
             src[j] = X2 + ((int64_t)((pc >> 2) * KC + (pc & 3)) * xs + m0 + 64 * q + lane);
             step[j] = 4 * xs;
-            dst[j] = 1024 + pc * 256 + 64 * q;
+            dst[j] = 1024 + pc * TB + 64 * q;
         }
     }
-    auto issue = [&](int s, int buf) {
+    auto issue = [&](int s, int buf) {                     // stage s -> LDS buffer buf
 #pragma unroll
-        for (int j = 0; j < 6; ++j)
+        for (int j = 0; j < PW; ++j)
             __builtin_amdgcn_global_load_lds(src[j] + s * step[j],
-                                             (__attribute__((address_space(3))) void*)(h2g_lds + buf * H2G_STAGE_UNITS + dst[j]), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(h2g_lds + buf * STAGE_UNITS + dst[j]), 16, 0, 0);
     };
     const int r = lane & 15, kq = lane >> 4, wf = w & 1, wt = w >> 1;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)h2g_lds;
     const uint32_t aW = lds0 + 16u * (uint32_t)(kq * 128 + 64 * wf + r);
-    const uint32_t aX = lds0 + 16u * (uint32_t)(1024 + kq * 256 + 64 * wt + r);
+    const uint32_t aX = lds0 + 16u * (uint32_t)(1024 + kq * TB + 64 * wt + r);
+    constexpr int XLO = 64 * TB;                           // byte offset of the lo plane inside the X part: 4 chunks x TB rows x 16
 
     h2_f32x4 acc1[4][4], acc2[4][4];
 #pragma unroll
@@ -279,22 +336,38 @@ __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict_
             acc2[i][j] = h2_f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
+    H2_DBG(unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long wall0 = __builtin_amdgcn_s_memrealtime();)
+    H2_STAMP(tp0);
+    // the SIMD's second wave (w >= 4) issues its pieces behind its MFMAs, the first one under the latency of its reads
+    const bool late = stagger && w >= 4;
     issue(0, 0);
     if (KS > 1) issue(1, 1);
     int buf = 0;
+    H2_STAMP(tp1);
+    H2_DBG(dbg[0] = tp1 - tp0;)
+#define H2_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h2_f16x8, A), __builtin_bit_cast(h2_f16x8, B), C, 0, 0, 0)
     for (int s = 0; s < KS; ++s) {
+        H2_STAMP(t0);
+        // stage s has landed: the only pieces that may still fly are those of stage s + 1
         if (s + 1 < KS) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (s + 2 < KS) issue(s + 2, buf >= 1 ? buf - 1 : 2);         // (s + 2) % 3
-        const uint32_t bW = aW + (uint32_t)buf * (H2G_STAGE_UNITS * 16), bX = aX + (uint32_t)buf * (H2G_STAGE_UNITS * 16);
+        H2_STAMP(t1);
+        const uint32_t bW = aW + (uint32_t)buf * (STAGE_UNITS * 16), bX = aX + (uint32_t)buf * (STAGE_UNITS * 16);
         h2_u32x4 wh[4], wl[4], xh[4], xl[4];
         H2_READ(wh[0], bW, 0); H2_READ(wh[1], bW, 256); H2_READ(wh[2], bW, 512); H2_READ(wh[3], bW, 768);
         H2_READ(xh[0], bX, 0); H2_READ(xh[1], bX, 256); H2_READ(xh[2], bX, 512); H2_READ(xh[3], bX, 768);
-        H2_READ(xl[0], bX, 16384); H2_READ(xl[1], bX, 16384 + 256); H2_READ(xl[2], bX, 16384 + 512); H2_READ(xl[3], bX, 16384 + 768);
+        H2_READ(xl[0], bX, XLO); H2_READ(xl[1], bX, XLO + 256); H2_READ(xl[2], bX, XLO + 512); H2_READ(xl[3], bX, XLO + 768);
         H2_READ(wl[0], bW, 8192); H2_READ(wl[1], bW, 8192 + 256); H2_READ(wl[2], bW, 8192 + 512); H2_READ(wl[3], bW, 8192 + 768);
+        __builtin_amdgcn_sched_barrier(0);
+        H2_STAMP(t2);
+        // the pieces of stage s + 2 go into the buffer of the stage multiplied in step s - 1 (every wave is past it)
+        if (!late && s + 2 < KS) issue(s + 2, buf == 0 ? 2 : buf - 1);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(wh[0]), "+v"(wh[1]), "+v"(wh[2]), "+v"(wh[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]) :: "memory");
-#define H2_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h2_f16x8, A), __builtin_bit_cast(h2_f16x8, B), C, 0, 0, 0)
+        H2_DBG(__builtin_amdgcn_sched_barrier(0);)
+        H2_STAMP(t3);
+        H2_DBG(__builtin_amdgcn_sched_barrier(0);)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -309,56 +382,75 @@ __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict_
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) H2_MFMA(wl[i], xh[j], acc2[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        H2_STAMP(t4);
+        if (late && s + 2 < KS) issue(s + 2, buf == 0 ? 2 : buf - 1);
+        H2_STAMP(t5);
+        H2_DBG(dbg[1] += t1 - t0; dbg[2] += t5 - t4; dbg[3] += t3 - t1; dbg[4] += t4 - t3; dbg[6] += 1;)
         buf = buf == 2 ? 0 : buf + 1;
     }
+    H2_STAMP(te0);
 
-    // ---- epilogue
-    bool bad = false;
+    // ---- epilogue (pairs of values on the packed fp32 pipe; 32-bit byte offsets from the output's base)
+    float amax = 0.f;                                      // max |value split to fp16|: one range test per lane at the end
     {
         // acc[i][j][e]: feature n0 + 64 wf + 16 i + 4 kq + e, token m0 + 64 wt + 16 j + r
+        const uint32_t os32 = (uint32_t)os, lo_plane = (uint32_t)(N >> 3) * os32 * 16u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = n0 + 64 * wf + 16 * i + 4 * kq;
             const h2_f32x4 bv = *reinterpret_cast<const h2_f32x4*>(bias + f);
+            const h2_f32x2 b01 = {bv[0], bv[1]}, b23 = {bv[2], bv[3]}, c2 = {CE_H2_INV_SCALE, CE_H2_INV_SCALE};
+            const bool scaled = EPI == CE_H2_EPI_H2 && f < qcols;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int t = m0 + 64 * wt + 16 * j + r;
-                h2_f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = __builtin_fmaf(acc2[i][j][e], CE_H2_INV_SCALE, acc1[i][j][e]) + bv[e];
-                    if (EPI == CE_H2_EPI_GELU_H2) v[e] = h2_gelu(v[e]);
-                    if (EPI == CE_H2_EPI_H2 && f < qcols) v[e] *= qscale;
+                h2_f32x2 v01 = __builtin_elementwise_fma(h2_f32x2{acc2[i][j][0], acc2[i][j][1]}, c2, h2_f32x2{acc1[i][j][0], acc1[i][j][1]}) + b01;
+                h2_f32x2 v23 = __builtin_elementwise_fma(h2_f32x2{acc2[i][j][2], acc2[i][j][3]}, c2, h2_f32x2{acc1[i][j][2], acc1[i][j][3]}) + b23;
+                if (EPI == CE_H2_EPI_GELU_H2) {
+                    v01 = h2_gelu2(v01);
+                    v23 = h2_gelu2(v23);
+                }
+                if (scaled) {
+                    v01 *= h2_f32x2{qscale, qscale};
+                    v23 *= h2_f32x2{qscale, qscale};
                 }
                 if (t >= M) continue;
                 if (EPI == CE_H2_EPI_F32) {
-                    *reinterpret_cast<h2_f32x4*>(out32 + (int64_t)t * N + f) = v;
+                    *reinterpret_cast<h2_f32x4*>(out32 + (int64_t)t * N + f) = h2_f32x4{v01[0], v01[1], v23[0], v23[1]};
                 } else {
-                    h2_f16x4 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const h2_pair p = h2_split(v[e]);
-                        hi[e] = p.hi;
-                        lo[e] = p.lo;
-                        bad |= h2_out_of_range(v[e]);
-                    }
-                    const int64_t u = (int64_t)(f >> 3) * os + t;                  // unit (chunk f / 8, token), half kq & 1
-                    out2[2 * u + (kq & 1)] = __builtin_bit_cast(h2_u32x2, hi);
-                    out2[2 * ((int64_t)(N >> 3) * os + u) + (kq & 1)] = __builtin_bit_cast(h2_u32x2, lo);
+                    h2_f16x2 h01, l01, h23, l23;
+                    h2_split2(v01, h01, l01);
+                    h2_split2(v23, h23, l23);
+                    amax = h2_vmax3(amax, __builtin_fabsf(v01[0]), __builtin_fabsf(v01[1]));
+                    amax = h2_vmax3(amax, __builtin_fabsf(v23[0]), __builtin_fabsf(v23[1]));
+                    // unit (chunk f / 8, token), half kq & 1
+                    const uint32_t off = ((uint32_t)(f >> 3) * os32 + (uint32_t)t) * 16u + 8u * (uint32_t)(kq & 1);
+                    *reinterpret_cast<h2_u32x2*>((char*)out2 + off) = h2_u32x2{__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23)};
+                    *reinterpret_cast<h2_u32x2*>((char*)out2 + lo_plane + off) = h2_u32x2{__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23)};
                 }
             }
         }
     }
+    const bool bad = !(amax <= 65504.f);                   // (a NaN never raises amax: it comes out of an overflow flagged before it)
     if (EPI != CE_H2_EPI_F32) h2_raise(bad, flag);
+#ifdef RR_DEBUG_HARNESS
+    if (blockIdx.x == 2048 && K == 384 && N == 1536 && (w == 0 || w == 4) && lane == 0) {
+        dbg[5] = __builtin_amdgcn_s_memtime() - te0;
+        dbg[7] = __builtin_amdgcn_s_memrealtime() - wall0;
+        for (int i = 0; i < 8; ++i) h2_dbg[w >> 2][i] = dbg[i];
+    }
+#endif
 }
 
 void ce_h2_gemm(int epi, const void* W2, int N, const void* X2, int64_t xs, int M, int K, const float* bias, float* out32,
                 void* out2, int64_t os, unsigned* flag, hipStream_t st, float qscale, int qcols) {
+    static const int stagger = getenv("RR_CE_H2_NO_STAGGER") == nullptr;      // (A/B)
     const int tbs = (M + H2G_BT - 1) / H2G_BT;
     const dim3 grid((unsigned)(((tbs + 7) / 8) * 8 * (N / H2G_BF)));
 #define H2_LAUNCH(E) \
     hipLaunchKernelGGL((ce_gemm_h2<E>), grid, dim3(512), H2G_LDS, st, (const h2_u32x4*)W2, N, (const h2_u32x4*)X2, xs, M, K, bias, out32, \
-                       (h2_u32x2*)out2, os, flag, qscale, qcols)
+                       (h2_u32x2*)out2, os, flag, qscale, qcols, stagger)
     if (epi == CE_H2_EPI_F32) H2_LAUNCH(CE_H2_EPI_F32);
     else if (epi == CE_H2_EPI_H2) H2_LAUNCH(CE_H2_EPI_H2);
     else H2_LAUNCH(CE_H2_EPI_GELU_H2);
@@ -376,8 +468,8 @@ void ce_h2_gemm(int epi, const void* W2, int N, const void* X2, int64_t xs, int 
 //     operand of lane (key r, chunk kq) is one ds_read_b128, conflict-free under the swizzle;
 //     s = s1 + s2 / 2048, s1 = Khi Qhi, s2 = Khi Qlo + Klo Qhi;
 //   online softmax in base 2; a lane holds the 8 scores of ITS query against keys 16 a + 4 (l >> 4) + e (a = 0, 1), the row
-//     maximum is two v_permlane swaps away; p = 2^(s - m + 15) -- the 2^15 keeps a probability down to 2e-9 a normal fp16 (below,
-//     the matrix core reads 0: <= 2e-9 per key, against fp32's own 6e-8 on the largest); it cancels in o / l;
+//     maximum is two v_permlane swaps away; p = 2^(s - m + 15) -- the 2^15 keeps a probability down to 2e-9 a normal fp16 and
+//     one down to 2e-12 a subnormal one with its rest in lo (fp32's own rounding of the row is 6e-8); it cancels in o / l;
 //   O^T[dim][query] += V^T P^T: the lane's 8 probabilities ARE the B operand's k slots 8 (l >> 4) + 4 a + e, so P never leaves
 //     its registers, and the A operand -- dim (l & 15) against exactly those keys -- is two ds_read_b64_tr_b16 of the row-major
 //     V image (the hardware transpose: 4 keys x 16 dims per 16 lanes), conflict-free under the same swizzle;
@@ -389,8 +481,6 @@ void ce_h2_gemm(int epi, const void* W2, int N, const void* X2, int64_t xs, int 
 #define H2A_LDS (H2A_MAX_GROUPS * H2A_GROUP_UNITS * 16)
 #define H2A_CHUNKS 144                                          // 16-byte units per token and plane: 1152 / 8
 typedef __fp16 h2_tr4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-
-typedef float h2_f32x2 __attribute__((ext_vector_type(2)));
 
 // NT query tiles of one wave (tiles qt0, qt0 + 8, ...) against every key group, their chains interleaved in one instruction
 // stream: a tile's chain is MFMA -> vector -> MFMA, each step waiting for the one before; with one tile per pass the wave
@@ -422,7 +512,10 @@ __device__ __forceinline__ void h2a_tiles(const h2_u32x4* __restrict__ qkv, int6
         mm[t] = -INFINITY;
         lsum[t] = h2_f32x2{0.f, 0.f};
     }
-    for (int gi = 0; gi < ng; ++gi) {
+    // one key group; MASKED = the sequence's last, partial group (its own copy of the body: no mask work, and no branch between
+    // the four tiles' chains, in the groups before it)
+    auto group = [&](int gi, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
         const h2_u32x4* kb = kimg + gi * H2A_GROUP_UNITS;
         h2_f16x8 kh[2], kl[2];
 #pragma unroll
@@ -432,7 +525,6 @@ __device__ __forceinline__ void h2a_tiles(const h2_u32x4* __restrict__ qkv, int6
         }
         h2_f32x2 s[NT][4];                                 // [a][e pair]: keys 16 a + 4 kq + 2 j, + 1
         float cm[NT];
-        const bool last = 32 * gi + 32 > S;                // (wave-uniform) the sequence's last group holds padding keys
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -445,7 +537,7 @@ __device__ __forceinline__ void h2a_tiles(const h2_u32x4* __restrict__ qkv, int6
                 s[t][2 * a] = __builtin_elementwise_fma(h2_f32x2{s2[0], s2[1]}, c, h2_f32x2{s1[0], s1[1]});
                 s[t][2 * a + 1] = __builtin_elementwise_fma(h2_f32x2{s2[2], s2[3]}, c, h2_f32x2{s1[2], s1[3]});
             }
-            if (last) {
+            if (MASKED) {
                 const int key0 = 32 * gi + 4 * kq;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -486,12 +578,12 @@ __device__ __forceinline__ void h2a_tiles(const h2_u32x4* __restrict__ qkv, int6
                 const h2_f32x2 d = s[t][j] - m2;
                 const h2_f32x2 pe = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};      // masked keys: 2^-inf = 0
                 lsum[t] += pe;
-                const _Float16 h0 = (_Float16)pe[0], h1 = (_Float16)pe[1];
-                ph[t][2 * j] = h0;
-                ph[t][2 * j + 1] = h1;
-                const h2_f32x2 rr = (pe - h2_f32x2{(float)h0, (float)h1}) * h2_f32x2{CE_H2_SCALE, CE_H2_SCALE};
-                pl[t][2 * j] = (_Float16)rr[0];
-                pl[t][2 * j + 1] = (_Float16)rr[1];
+                h2_f16x2 h2v, l2v;
+                h2_split2(pe, h2v, l2v);
+                ph[t][2 * j] = h2v[0];
+                ph[t][2 * j + 1] = h2v[1];
+                pl[t][2 * j] = l2v[0];
+                pl[t][2 * j + 1] = l2v[1];
             }
         }
         const char* vb = vimg + gi * (H2A_GROUP_UNITS * 16);
@@ -518,7 +610,10 @@ __device__ __forceinline__ void h2a_tiles(const h2_u32x4* __restrict__ qkv, int6
 #pragma unroll
             for (int t = 0; t < NT; ++t) o2[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t], o2[t][i], 0, 0, 0);
         }
-    }
+    };
+    const int ng_full = S >> 5;
+    for (int gi = 0; gi < ng_full; ++gi) group(gi, std::false_type{});
+    if (ng_full < ng) group(ng_full, std::true_type{});
     // ---- the row sum over the query's four lanes, normalise, split, store: o[i][e] = dim 16 i + 4 kq + e of query 16 qt + r
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -600,10 +695,19 @@ void ce_h2_attention(const void* qkv, int64_t xs, const int32_t* cu, int n_seqs,
 }
 
 int ce_h2_set_attributes() {
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_H2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<CE_H2_EPI_GELU_H2>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS));
+#define H2_ATTR(E) RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_gemm_h2<E>, hipFuncAttributeMaxDynamicSharedMemorySize, H2G_LDS))
+    H2_ATTR(CE_H2_EPI_F32);
+    H2_ATTR(CE_H2_EPI_H2);
+    H2_ATTR(CE_H2_EPI_GELU_H2);
+#undef H2_ATTR
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2A_LDS));
     return RR_OK;
 }
 
+#ifdef RR_DEBUG_HARNESS
+extern "C" int rr_debug_ce_h2_stamps(unsigned long long* out16) {
+    RR_HIP_TRY(hipDeviceSynchronize());
+    RR_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(h2_dbg), sizeof(unsigned long long) * 16));
+    return RR_OK;
+}
+#endif

@@ -15,5 +15,7 @@ int rr_debug_scan_flt(rr_index* ix, int32_t variant, int32_t reps, float* out_ms
 int rr_debug_fltq_compare(rr_index* ix, int64_t* out);
 // tools/k5_stamps.py: in-kernel phase clocks of the last ce_ffn_fused launch (rr_ce.hip)
 int rr_debug_ce_ffn_stamps(unsigned long long* out20);
+// tools/k5_h2_stamps.py: phase clocks of one workgroup of the last FFN1 ce_gemm_h2 launch (rr_ce_h2.hip)
+int rr_debug_ce_h2_stamps(unsigned long long* out16);
 }
 #endif
