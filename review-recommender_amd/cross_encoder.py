@@ -8,7 +8,8 @@ Drop-ins for the two sentence-transformers objects the reference holds:
       app/app_product_search.py:53-69,250-251; app/test.py:91-94,232
 
 Both run csrc/rr_ce.hip through the C ABI (rr_ce_create / rr_ce_forward_dev), in one of two precisions: "fp32" (default:
-the reference's arithmetic, fp32 operands on the fp32-input matrix instructions, within 1e-5 of `transformers`) or "bf16"
+the reference's arithmetic: every fp32 operand as two fp16 numbers, three matrix-core products per fp32 product, within 1e-5
+of `transformers`) or "bf16"
 (the fast path: bf16 MFMA GEMMs + attention, fp32 residual stream).  Weights come from a local state dict (Hugging Face BERT names: a
 `model.safetensors` / `pytorch_model.bin` directory, or a dict of arrays); text is tokenised by
 wordpiece.WordPieceTokenizer from a local vocab.txt.  Without a vocabulary on disk the pre-tokenised entry
@@ -59,9 +60,10 @@ class BertEncoderGPU:
 
     def __init__(self, state_dict: Dict, *, device: int = 0, ln_eps: float = 1e-12, with_head: bool = True,
                  max_tokens_per_call: int = 131_072, precision: str = "fp32"):
-        """``precision``: "fp32" = the reference's arithmetic (fp32 weights and activations on the fp32-input matrix
-        instructions: logits / embeddings within 1e-5 of `transformers`), "bf16" = the fast path (bf16 operands, fp32
-        accumulation: 2.5e-2 on O(1) logits, ~10x the throughput).  include/rr_hip.h: RR_CE_PRECISION_*."""
+        """``precision``: "fp32" = the reference's arithmetic (fp32 weights and activations, products on the fp16 matrix
+        cores as exact as an fp32 multiply-add chain: logits / embeddings within 1e-5 of `transformers`; a value beyond
+        fp16's range switches the handle to the wide-range kernels, see `out_of_range`), "bf16" = the fast path (bf16
+        operands, fp32 accumulation: 2.5e-2 on O(1) logits, ~2.7x the throughput).  include/rr_hip.h: RR_CE_PRECISION_*."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         self.precision = precision

@@ -355,8 +355,9 @@ __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict_
         H2_STAMP(t1);
         const uint32_t bW = aW + (uint32_t)buf * (STAGE_UNITS * 16), bX = aX + (uint32_t)buf * (STAGE_UNITS * 16);
         h2_u32x4 wh[4], wl[4], xh[4], xl[4];
-        H2_READ(wh[0], bW, 0); H2_READ(wh[1], bW, 256); H2_READ(wh[2], bW, 512); H2_READ(wh[3], bW, 768);
+        // (X hi and the first W hi fragment first: four MFMAs can start once five of the sixteen fragments are there)
         H2_READ(xh[0], bX, 0); H2_READ(xh[1], bX, 256); H2_READ(xh[2], bX, 512); H2_READ(xh[3], bX, 768);
+        H2_READ(wh[0], bW, 0); H2_READ(wh[1], bW, 256); H2_READ(wh[2], bW, 512); H2_READ(wh[3], bW, 768);
         H2_READ(xl[0], bX, XLO); H2_READ(xl[1], bX, XLO + 256); H2_READ(xl[2], bX, XLO + 512); H2_READ(xl[3], bX, XLO + 768);
         H2_READ(wl[0], bW, 8192); H2_READ(wl[1], bW, 8192 + 256); H2_READ(wl[2], bW, 8192 + 512); H2_READ(wl[3], bW, 8192 + 768);
         __builtin_amdgcn_sched_barrier(0);
@@ -364,14 +365,21 @@ __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict_
         // the pieces of stage s + 2 go into the buffer of the stage multiplied in step s - 1 (every wave is past it)
         if (!late && s + 2 < KS) issue(s + 2, buf == 0 ? 2 : buf - 1);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(wh[0]), "+v"(wh[1]), "+v"(wh[2]), "+v"(wh[3]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]) :: "memory");
+        asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(wh[0]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]) :: "memory");
         H2_DBG(__builtin_amdgcn_sched_barrier(0);)
         H2_STAMP(t3);
         H2_DBG(__builtin_amdgcn_sched_barrier(0);)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) H2_MFMA(wh[0], xh[j], acc1[0][j]);
+        asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(wh[1]) :: "memory");
 #pragma unroll
-            for (int j = 0; j < 4; ++j) H2_MFMA(wh[i], xh[j], acc1[i][j]);
+        for (int j = 0; j < 4; ++j) H2_MFMA(wh[1], xh[j], acc1[1][j]);
+        asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(wh[2]) :: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) H2_MFMA(wh[2], xh[j], acc1[2][j]);
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(wh[3]) :: "memory");
+#pragma unroll
+        for (int j = 0; j < 4; ++j) H2_MFMA(wh[3], xh[j], acc1[3][j]);
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]) :: "memory");
 #pragma unroll
         for (int i = 0; i < 4; ++i)
