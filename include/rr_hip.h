@@ -277,8 +277,10 @@ typedef struct rr_ce_config {
 } rr_ce_config;
 /* RR_CE_PRECISION_BF16: Linear weights rounded once to bf16, bf16 MFMA operands, fp32 accumulation / residual / LayerNorm /
  * softmax / GELU: logits within 2.5e-2 of the fp32 reference on O(1) weights.  RR_CE_PRECISION_F32: what the reference runs
- * (fp32 torch, app/app_product_search.py:250-251, 277-278): fp32 weights and activations on the fp32-input matrix
- * instructions, exact erf / exp: logits and embeddings within 1e-5 of `transformers` (tests/test_gpu_k5.py), ~10x the time. */
+ * (fp32 torch, app/app_product_search.py:250-251, 277-278): fp32 weights and activations; every product on the fp16 matrix
+ * cores with both operands carried as two fp16 numbers (hi + lo / 2048, three products per fp32 product: as exact as an
+ * fp32 multiply-add chain, csrc/rr_ce_h2.hip), an fp32-grade GELU, base-2 softmax: logits and embeddings within 1e-5 of
+ * `transformers` (tests/test_gpu_k5.py), ~2.7x the time of the bf16 mode.  Its range: rr_ce_range_status below. */
 #define RR_CE_PRECISION_BF16 0
 #define RR_CE_PRECISION_F32 1
 /* Weights: fp32 host arrays in the layout of a Hugging Face BERT state dict (Linear weights are [out][in]), in this order:
@@ -288,7 +290,8 @@ typedef struct rr_ce_config {
  *     attention.output.dense.weight, .bias, attention.output.LayerNorm.weight, .bias,
  *     intermediate.dense.weight [FFN][H], .bias, output.dense.weight [H][FFN], .bias, output.LayerNorm.weight, .bias
  *   when n_labels > 0, four more: pooler.dense.weight [H][H], pooler.dense.bias, classifier.weight [n_labels][H], classifier.bias
- * Linear weights are rounded once to bf16 (nearest even) on the device (RR_CE_PRECISION_F32 also keeps them as given);
+ * Linear weights are rounded once to bf16 (nearest even) on the device (RR_CE_PRECISION_F32 also keeps them as given, and
+ * as fp16 pairs);
  * everything else stays fp32. */
 int rr_ce_create(int32_t device, const rr_ce_config* cfg, const float* const* h_tensors, int32_t n_tensors, rr_ce** out);
 int rr_ce_destroy(rr_ce* ce);

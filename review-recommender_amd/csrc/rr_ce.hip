@@ -1112,10 +1112,14 @@ __global__ void ce_to_bf16(const float* __restrict__ src, unsigned short* __rest
 // ------------------------------------------------------------------ reference-precision mode (RR_CE_PRECISION_F32)
 // The reference runs both encoders in fp32 torch (app/app_product_search.py:250-251, 277-278).  The kernels above multiply
 // in bf16 (2.5e-2 on logits of O(1)): the fast path.  This mode keeps every operand fp32 end to end -- fp32 weights, fp32
-// activations, the fp32-input matrix instruction v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation: the chip's
-// vector-rate matrix path, 157 TF/s), exact erf / exp / tanh of the device library -- so that logits and embeddings agree
-// with the `transformers` fixtures to fp32 rounding (1e-5, tests/test_gpu_k5.py).  Plain tiling, no fusion: this is the
-// parity mode, ~10x the time of the bf16 path.
+// activations -- so that logits and embeddings agree with the `transformers` fixtures to fp32 rounding (1e-5,
+// tests/test_gpu_k5.py).  Three generations of its products live in the library:
+//   * rr_ce_h2.hip (default since round 4): operands as two fp16 numbers, three MFMA products per fp32 product -- 13 ms per
+//     256 x 512 tokens; fp16's range guarded by a device flag (ce_forward_h2 below);
+//   * this file, ce_gemm_x3 / ce_attention_x3: operands as three bf16 terms, six products, ANY fp32 range -- 23.9 ms; what
+//     rr_ce_set_wide_range switches a handle to when the flag came up, and RR_CE_F32_SPLIT=bf16x3 for the A/B;
+//   * this file, ce_gemm_f32 / ce_attention_f32: the fp32-input matrix instruction v_mfma_f32_32x32x2_f32 (the chip's
+//     vector-rate matrix path, 157 TF/s) -- 35 ms; RR_CE_F32_MFMA=1 / RR_CE_F32_ATT_MFMA32=1 (A/B only).
 typedef float f32x16r __attribute__((ext_vector_type(16)));
 
 // out[M][N] = A[M][K] W[N][K]^T + bias (+ exact GELU); A, W, out fp32 row-major; N % 128 == 0, K % 16 == 0.
