@@ -277,7 +277,13 @@ __device__ unsigned long long h2_dbg[2][8];
 // and a step takes ~2 330 -- 300 - 500 until the first MFMA (eight waves read 128 KB of LDS at once), the pieces' issue
 // 190 - 300, ~150 at the barrier.  The epilogue (GELU + split + stores: ~11 000 cycles of vector work for the SIMD's two
 // waves) runs with the matrix pipe idle: 27 % of an FFN1 tile.  Also built and measured slower: the next stage's high-plane
-// fragments read one step ahead (every stage must then land within ONE step: 13.8 vs 13.1 ms per forward).
+// fragments read one step ahead (every stage must then land within ONE step: 13.8 vs 13.1 ms per forward); and a small-tile
+// form -- four waves, 128 x 128, 32x32x16 MFMAs, K step 16, four 16 KB stages, TWO independent workgroups per CU so that one
+// multiplies while the other reads, waits at its barrier or runs its epilogue: 13.6 ms (FFN-1 626 vs 613 us, QKV 435 vs 405).
+// That every re-cut lands within a few per cent says the phases are not what limits the kernel: the shader clock under it is
+// 1.5 GHz (stamps) of 2.4, i.e. the matrix peak at the clock it holds is 1.57 PF and FFN-2 runs at 1.1 PF, QKV at 0.85, FFN-1
+// (with its GELU) at 0.75 -- the power-bound regime rr_scan_fltq sits in, where cycles taken out of one
+// phase come back as a lower clock.  Less ENERGY per product (fewer LDS bytes per MFMA: wider wave tiles) is what would move it.
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void ce_gemm_h2(const h2_u32x4* __restrict__ W2, int N, const h2_u32x4* __restrict__ X2, int64_t xs, int M,
                                                      int K, const float* __restrict__ bias, float* __restrict__ out32,
