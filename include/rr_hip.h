@@ -310,7 +310,8 @@ int rr_ce_last_forward_ms(rr_ce* ce, float* out_ms);
 /* RR_CE_PRECISION_F32 multiplies on the fp16 matrix cores: every fp32 operand as hi + lo / 2048 in two fp16 numbers, three
  * products per fp32 product (csrc/rr_ce_h2.hip; as exact as an fp32 multiply-add chain).  fp16 ends at 65504: a forward pass
  * that meets a larger activation raises a flag on the device, writes NaN logits / CLS rows for the whole call (never a wrong
- * finite number) and reports it here -- *out_of_range = 1 -- once the pass has finished (this call waits for it).
+ * finite number; RR_CE_OUT_HIDDEN rows are left as computed: ask here) and reports it here -- *out_of_range = 1 -- once
+ * the pass has finished (this call waits for it).
  * rr_ce_set_wide_range(ce, 1) switches the handle to three bf16 terms per operand and six products (any fp32 range,
  * ~1.6 x the time): run the pass again after it.  cross_encoder.py does both by itself on the host path. */
 int rr_ce_range_status(rr_ce* ce, int32_t* out_of_range);

@@ -1945,6 +1945,7 @@ static int ce_reserve_f32(rr_ce* ce, int64_t tokens) {
     if (e == hipSuccess) e = hipMemset(ce->ctxh, 0, n * CE_H * 4);
     if (e == hipSuccess) e = hipMemset(ce->inter32, 0, n * CE_FFN * 4);
     if (e == hipSuccess) e = hipMemset(ce->qkv32, 0, n * 3 * CE_H * 4);
+    if (e == hipSuccess) e = hipDeviceSynchronize();      // (the fills run on the NULL stream: a non-blocking caller stream would not wait for them)
     if (e != hipSuccess) { rr_set_error("rr_ce_forward: fp32 activation scratch for %lld tokens: %s", (long long)tokens, hipGetErrorString(e)); return RR_E_NOMEM; }
     ce->cap32 = (int64_t)n;
     return RR_OK;
@@ -1968,6 +1969,7 @@ static int ce_reserve_seqs_f32(rr_ce* ce, int64_t seqs) {
     if (e == hipSuccess) e = hipMemset(ce->hxc, 0, n * CE_H * 4);
     if (e == hipSuccess) e = hipMemset(ce->ctxhc, 0, n * CE_H * 4);
     if (e == hipSuccess) e = hipMemset(ce->interhc, 0, n * CE_FFN * 4);
+    if (e == hipSuccess) e = hipDeviceSynchronize();      // (the fills run on the NULL stream: a non-blocking caller stream would not wait for them)
     if (e != hipSuccess) { rr_set_error("rr_ce_forward: compact fp32 scratch for %lld sequences: %s", (long long)seqs, hipGetErrorString(e)); return RR_E_NOMEM; }
     ce->cap32_seqs = (int64_t)n;
     return RR_OK;
