@@ -99,6 +99,7 @@ DEBUG_PROTOTYPES = {
     "rr_debug_fltq_compare": (C.c_int, [c_vp, P(c_i64)]),
     "rr_debug_ce_ffn_stamps": (C.c_int, [P(C.c_uint64)]),
     "rr_debug_ce_h2_stamps": (C.c_int, [P(C.c_uint64)]),
+    "rr_debug_ce_h2_gemm": (C.c_int, [c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, P(C.c_int32)]),
 }
 
 _lib = None

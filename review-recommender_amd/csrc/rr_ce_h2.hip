@@ -722,6 +722,48 @@ int ce_h2_set_attributes() {
 }
 
 #ifdef RR_DEBUG_HARNESS
+// h2 image -> fp32 rows (the inverse of ce_h2_pack: hi + lo / 2048), for the harness's GEMM check
+__global__ __launch_bounds__(256) void ce_h2_unpack_kernel(const h2_u32x4* __restrict__ src, int R, int K, int64_t rs, float* __restrict__ dst) {
+    const int KC = K >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)R * KC) return;
+    const int row = (int)(i % R), kc = (int)(i / R);
+    const h2_f16x8 hi = __builtin_bit_cast(h2_f16x8, src[(int64_t)kc * rs + row]), lo = __builtin_bit_cast(h2_f16x8, src[((int64_t)KC + kc) * rs + row]);
+    for (int e = 0; e < 8; ++e) dst[(int64_t)row * K + 8 * kc + e] = (float)hi[e] + (float)lo[e] * CE_H2_INV_SCALE;
+}
+
+// tests/test_gpu_k5.py (child process on librr_hip_dbg.so): out[M][N] = x[M][K] w[N][K]^T + bias through ce_h2_pack +
+// ce_gemm_h2, device pointers, fp32 row-major; epi = CE_H2_EPI_F32, or CE_H2_EPI_H2 / CE_H2_EPI_GELU_H2 with the h2 result
+// unpacked to fp32 (qscale 0.5 on the first `qcols` features for CE_H2_EPI_H2).  *flag_out = the range flag.
+extern "C" int rr_debug_ce_h2_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, const float* d_x, const float* d_w, const float* d_bias,
+                                   int32_t qcols, float* d_out, int32_t* flag_out) {
+    RR_REQUIRE(M >= 1 && N % 128 == 0 && K % 32 == 0 && d_x && d_w && d_bias && d_out && flag_out, "rr_debug_ce_h2_gemm: bad arguments");
+    if (int rc = ce_h2_set_attributes()) return rc;
+    const int64_t xs = rr_round_up(M, 256);
+    void *x2 = nullptr, *w2 = nullptr, *o2 = nullptr;
+    unsigned* flag = nullptr;
+    RR_HIP_TRY(hipMalloc(&x2, (size_t)xs * K * 4));
+    RR_HIP_TRY(hipMalloc(&w2, (size_t)N * K * 4));
+    RR_HIP_TRY(hipMalloc(&o2, (size_t)xs * N * 4));
+    RR_HIP_TRY(hipMalloc((void**)&flag, 4));
+    RR_HIP_TRY(hipMemset(x2, 0, (size_t)xs * K * 4));
+    RR_HIP_TRY(hipMemset(flag, 0, 4));
+    ce_h2_pack(d_x, M, K, x2, xs, nullptr);
+    ce_h2_pack(d_w, N, K, w2, N, nullptr);
+    ce_h2_gemm(epi, w2, N, x2, xs, M, K, d_bias, d_out, o2, xs, flag, nullptr, 0.5f, qcols);
+    if (epi != CE_H2_EPI_F32) {
+        const int64_t n = (int64_t)M * (N / 8);
+        hipLaunchKernelGGL(ce_h2_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const h2_u32x4*)o2, M, N, xs, d_out);
+    }
+    RR_HIP_TRY(hipDeviceSynchronize());
+    unsigned f = 0;
+    RR_HIP_TRY(hipMemcpy(&f, flag, 4, hipMemcpyDeviceToHost));
+    *flag_out = (int32_t)f;
+    hipFree(x2); hipFree(w2); hipFree(o2); hipFree(flag);
+    RR_HIP_TRY(hipGetLastError());
+    return RR_OK;
+}
+
 extern "C" int rr_debug_ce_h2_stamps(unsigned long long* out16) {
     RR_HIP_TRY(hipDeviceSynchronize());
     RR_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(h2_dbg), sizeof(unsigned long long) * 16));

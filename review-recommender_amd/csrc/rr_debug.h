@@ -17,5 +17,8 @@ int rr_debug_fltq_compare(rr_index* ix, int64_t* out);
 int rr_debug_ce_ffn_stamps(unsigned long long* out20);
 // tools/k5_h2_stamps.py: phase clocks of one workgroup of the last FFN1 ce_gemm_h2 launch (rr_ce_h2.hip)
 int rr_debug_ce_h2_stamps(unsigned long long* out16);
+// tests/test_gpu_k5.py: one ce_gemm_h2 product on caller data (pack -> GEMM -> fp32), see the definition
+int rr_debug_ce_h2_gemm(int32_t epi, int32_t M, int32_t N, int32_t K, const float* d_x, const float* d_w, const float* d_bias, int32_t qcols,
+                        float* d_out, int32_t* flag_out);
 }
 #endif

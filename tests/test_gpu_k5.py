@@ -391,3 +391,76 @@ def test_fp32_mode_two_splits_agree_and_a_value_beyond_fp16_switches_the_handle(
         got = auto.predict_ids(seqs)
     assert np.array_equal(got, want)
     assert not auto.model.out_of_range()                     # (the handle now runs the wide-range kernels)
+
+
+H2_GEMM_CHILD = r"""
+import os, sys
+os.environ["RR_DEBUG_HARNESS"] = "1"
+sys.path.insert(0, %r)
+import ctypes as C
+import numpy as np, torch
+from scipy.special import erf
+from review_recommender_amd import _lib
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(21)
+EPI_F32, EPI_H2, EPI_GELU = 0, 1, 2
+def run(epi, M, N, K, x, w, b, qcols=0):
+    dx, dw, db = (torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev) for a in (x, w, b))
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    flag = C.c_int32(-1)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.rr_debug_ce_h2_gemm(epi, M, N, K, p(dx), p(dw), p(db), qcols, p(out), C.byref(flag)), "rr_debug_ce_h2_gemm")
+    return out.cpu().numpy().astype(np.float64), flag.value
+cases = [("out-proj shape, ragged M", EPI_F32, 1000, 384, 384), ("FFN-2 shape", EPI_F32, 517, 384, 1536), ("one token", EPI_F32, 1, 128, 32),
+         ("QKV shape, h2 out, Q scaled", EPI_H2, 700, 1152, 384), ("FFN-1 shape, GELU", EPI_GELU, 300, 1536, 384)]
+for name, epi, M, N, K in cases:
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    # a tenth of the entries around and below fp16's subnormal range, some exact zeros
+    tiny = rng.random((M, K)) < 0.1
+    x[tiny] = (10.0 ** rng.uniform(-9, -4, tiny.sum()) * rng.choice([-1, 1], tiny.sum())).astype(np.float32)
+    x[rng.random((M, K)) < 0.01] = 0.0
+    b = rng.standard_normal(N).astype(np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    mag = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+    qcols = 384 if epi == EPI_H2 else 0
+    if epi == EPI_H2:
+        ref[:, :qcols] *= 0.5; mag[:, :qcols] *= 0.5
+    if epi == EPI_GELU:
+        ref = 0.5 * ref * (1.0 + erf(ref / np.sqrt(2.0)))
+    got, flag = run(epi, M, N, K, x, w, b, qcols)
+    f32 = (torch.from_numpy(x).to(dev) @ torch.from_numpy(w).to(dev).T).cpu().numpy().astype(np.float64) + b
+    e_f32 = np.abs(f32 - (x.astype(np.float64) @ w.astype(np.float64).T + b)).max() if epi == EPI_F32 else float("nan")
+    print("CASE|%%s|%%d|%%.3e|%%.3e|%%d" %% (name, flag, float((np.abs(got - ref) / mag).max()), float(e_f32 / mag.max()), int(np.isfinite(got).all())))
+# a value beyond fp16's range in an h2 result raises the flag; an fp32 result of the same product does not split anything
+x = np.full((4, 32), 300.0, np.float32); w = np.full((128, 32), 10.0, np.float32); b = np.zeros(128, np.float32)
+_, flag_h2 = run(EPI_H2, 4, 128, 32, x, w, b)
+got, flag_f32 = run(EPI_F32, 4, 128, 32, x, w, b)
+print("RANGE|%%d|%%d|%%.1f" %% (flag_h2, flag_f32, got[0, 0]))
+"""
+
+
+def test_h2_gemm_kernel_against_float64_products():
+    """ce_gemm_h2 by itself (through the harness library, in a child process): packed operands -> three fp16 products ->
+    the three epilogues, on the model's four GEMM shapes with ragged token counts, a tenth of the activations in and below
+    fp16's SUBNORMAL range (1e-9 .. 1e-4) and exact zeros.  Every output within 3e-7 of sum |x w| of the float64 product
+    (an fp32 GEMM of the same data: ~1e-7; the h2 epilogues add one fp16-pair rounding, 2^-22); GELU against the float64 erf
+    form within 6e-7; the range flag up exactly when a value that is SPLIT leaves fp16's range."""
+    from review_recommender_amd.build import DEBUG_LIB_PATH
+    import pathlib
+    import subprocess
+    import sys
+    if not DEBUG_LIB_PATH.exists():
+        pytest.skip("librr_hip_dbg.so not built (python review-recommender_amd/build.py --debug)")
+    root = str(pathlib.Path(__file__).resolve().parent.parent)
+    p = subprocess.run([sys.executable, "-c", H2_GEMM_CHILD % root], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    cases = [l.split("|") for l in p.stdout.splitlines() if l.startswith("CASE|")]
+    assert len(cases) == 5, p.stdout
+    for _, name, flag, err, err_f32, finite in cases:
+        print(name, "error / sum|xw|:", err, " fp32 GEMM:", err_f32)
+        assert int(flag) == 0 and int(finite) == 1, name
+        assert float(err) < (6e-7 if "GELU" in name else 3e-7), (name, err)
+    rng_line = [l.split("|") for l in p.stdout.splitlines() if l.startswith("RANGE|")][0]
+    assert int(rng_line[1]) == 1 and int(rng_line[2]) == 0 and float(rng_line[3]) == 96000.0
