@@ -502,7 +502,8 @@ typedef __fp16 h2_tr4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 // launch, ~4.4 cycles each with exp2 at 8) plus 8 of every MFMA's 16 cycles, in which the SIMD issues no vector instruction
 // (MI355X_MICROARCH.md) -- 630 k + 145 k of the 885 k cycles a launch takes.  A form that issues the next key group's K Q^T
 // MFMAs inside the exp2 / split stretch of the current one (software-pipelined by one group, two tiles per pass) was built
-// and ran at the same speed: the two pipes already overlap as far as the issue rule lets them.
+// and ran at the same speed, and so did the split of P by v_fma_mixlo / mixhi_f16 (four vector instructions per pair instead
+// of six, the same bits): the instruction count of one phase is not what sets this kernel's time either.
 template <int NT>
 __device__ __forceinline__ void h2a_tiles(const h2_u32x4* __restrict__ qkv, int64_t xs, int t0, int S, int ng, int head, int qt0, int n_tiles,
                                           const h2_u32x4* kimg, const char* vimg, int vdi, int r, int kq, h2_u32x2* __restrict__ ctx2,
