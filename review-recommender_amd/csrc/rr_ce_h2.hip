@@ -216,21 +216,7 @@ void ce_h2_add_ln(const float* y, float* h32, int T, const float* g, const float
 // weighted minimax fit on [0, 4.25], the argument clamped there -- erfc(4.25) = 1.8e-9): no branch, one v_exp_f32, 13 vector
 // operations against ~40 for the library's erff, which made the FFN's first GEMM vector-bound.  In fp32 with this operation
 // order: |error| <= 2.5e-7 (8.9e-8 of max(1, |x|)) against the float64 value, where torch's own fp32 gelu sits at 1.2e-6.
-__device__ __forceinline__ float h2_gelu(float x) {
-    const float a = __builtin_fabsf(x);
-    const float t = __builtin_fminf(a * 0.70710678118654752440f, 4.25f);
-    float p = -3.043266588e-05f;
-    p = __builtin_fmaf(p, t, 3.174242738e-04f);
-    p = __builtin_fmaf(p, t, -1.051770989e-03f);
-    p = __builtin_fmaf(p, t, -1.539122313e-03f);
-    p = __builtin_fmaf(p, t, 2.898171730e-02f);
-    p = __builtin_fmaf(p, t, -1.488533765e-01f);
-    p = __builtin_fmaf(p, t, -9.183242917e-01f);
-    p = __builtin_fmaf(p, t, -1.627916813e+00f);
-    const float e = __builtin_amdgcn_exp2f(p * t);
-    return __builtin_fmaf(-0.5f * a, e, __builtin_fmaxf(x, 0.f));
-}
-// two values at a time: the Horner steps, the products and the last step on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32)
+// Two values at a time: the Horner steps, the products and the last step on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32).
 __device__ __forceinline__ h2_f32x2 h2_gelu2(h2_f32x2 x) {
     const h2_f32x2 a = {__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
     const h2_f32x2 t = {__builtin_fminf(a[0] * 0.70710678118654752440f, 4.25f), __builtin_fminf(a[1] * 0.70710678118654752440f, 4.25f)};
