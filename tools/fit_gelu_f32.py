@@ -14,7 +14,7 @@ from numpy.polynomial import chebyshev as C
 from scipy.special import erfc
 
 T_MAX = 4.25
-DEG = int(sys.argv[1]) if len(sys.argv) > 1 else 7       # degree of P (q has degree DEG + 1)
+DEG = 7                                                  # degree of P (q has degree DEG + 1); the kernel's
 
 
 def fit(deg):
@@ -69,7 +69,7 @@ def gelu_kernel(x, coef_t):
 
 if __name__ == "__main__":
     from scipy.special import erf
-    for deg in ([DEG] if len(sys.argv) > 1 else [5, 6, 7, 8, 9]):
+    for deg in ([int(sys.argv[1])] if len(sys.argv) > 1 else [5, 6, 7, 8, 9]):
         coef_u, fit_err = fit(deg)
         coef_t = powers_of_t(coef_u)
         x = np.concatenate([np.linspace(-10, 10, 4_000_001), np.linspace(-0.02, 0.02, 40001)])
