@@ -1,7 +1,8 @@
-"""The arithmetic of the reference-precision encoder restated on the CPU.  (1) Its fp32-grade GELU (csrc/rr_ce_h2.hip: h2_gelu2) on the CPU: the coefficients in the
-kernel source are the ones tools/fit_gelu_f32.py produces, and the formula -- evaluated in float32 with the kernel's operation
-order -- stays within fp32 rounding of the erf form the reference computes (torch's `gelu`, app/app_product_search.py:277-278
-through BertIntermediate)."""
+"""The arithmetic of the reference-precision encoder (csrc/rr_ce_h2.hip) restated on the CPU.
+(1) Its fp32-grade GELU (h2_gelu2): the coefficients in the kernel source are the ones tools/fit_gelu_f32.py produces, and
+    the formula -- evaluated in float32 with the kernel's operation order -- stays within fp32 rounding of the erf form the
+    reference computes (torch's `gelu` inside BertIntermediate, app/app_product_search.py:277-278).
+(2) Its products: every fp32 operand as two fp16 numbers, three products per fp32 product."""
 import importlib.util
 import pathlib
 import re
