@@ -482,7 +482,7 @@ void ce_h2_gemm(int epi, const void* W2, int N, const void* X2, int64_t xs, int 
 #define H2A_CHUNKS 144                                          // 16-byte units per token and plane: 1152 / 8
 typedef __fp16 h2_tr4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-// NT query tiles of one wave (tiles qt0, qt0 + 8, ...) against every key group, their chains in one instruction stream (650 us
+// NT query tiles of one wave (tiles qt0, qt0 + TSTEP, ...) against every key group, their chains in one instruction stream (650 us
 // per layer at 131 072 tokens with one tile per pass, 590 with four; the K / V fragments are read once for the NT tiles).
 // The kernel is bound by the vector unit's ISSUE: ~93 vector instructions per 16 x 32 score tile (PMC: 143 k per SIMD and
 // launch, ~4.4 cycles each with exp2 at 8) plus 8 of every MFMA's 16 cycles, in which the SIMD issues no vector instruction
@@ -490,14 +490,14 @@ typedef __fp16 h2_tr4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 // MFMAs inside the exp2 / split stretch of the current one (software-pipelined by one group, two tiles per pass) was built
 // and ran at the same speed, and so did the split of P by v_fma_mixlo / mixhi_f16 (four vector instructions per pair instead
 // of six, the same bits): the instruction count of one phase is not what sets this kernel's time either.
-template <int NT>
+template <int NT, int TSTEP = 8>
 __device__ __forceinline__ void h2a_tiles(const h2_u32x4* __restrict__ qkv, int64_t xs, int t0, int S, int ng, int head, int qt0, int n_tiles,
                                           const h2_u32x4* kimg, const char* vimg, int vdi, int r, int kq, h2_u32x2* __restrict__ ctx2,
                                           int64_t os, int64_t cls_row, bool& bad) {
     h2_f16x8 bqh[NT], bql[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        int q = 16 * (qt0 + 8 * t) + r;
+        int q = 16 * (qt0 + TSTEP * t) + r;
         q = q < S ? q : S - 1;                            // (lanes / tiles past the sequence: a valid row, never stored)
         const h2_u32x4* p = qkv + ((int64_t)(head * 4 + kq) * xs + t0 + q);
         bqh[t] = __builtin_bit_cast(h2_f16x8, p[0]);
@@ -626,7 +626,7 @@ __device__ __forceinline__ void h2a_tiles(const h2_u32x4* __restrict__ qkv, int6
         l = __uint_as_float(x16[0]) + __uint_as_float(x16[1]);
         const auto x32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l), __float_as_uint(l), false, false);
         l = __uint_as_float(x32[0]) + __uint_as_float(x32[1]);
-        const int qt = qt0 + 8 * t, q = 16 * qt + r;
+        const int qt = qt0 + TSTEP * t, q = 16 * qt + r;
         if (qt < n_tiles && q < S && (cls_row < 0 || q == 0)) {
             const float inv = 1.0f / l;
             const int64_t row = cls_row >= 0 ? cls_row : t0 + q;
@@ -690,9 +690,61 @@ __global__ __launch_bounds__(512, 1) void ce_attention_h2(const h2_u32x4* __rest
     if (bad) atomicOr(flag, 1u);
 }
 
+// Short sequences (<= 64 tokens: the query encoder's 16-token queries): a whole workgroup per (sequence, head) is mostly
+// launch and barrier -- 24 576 workgroups of eight waves with one tile of work among them took 201 us per layer at 2048 x 16
+// tokens.  Here a WAVE owns a (sequence, head): it stages the one or two key groups into its own 16 KB of LDS (the same image,
+// no barrier: only this wave reads what its own LDS-DMA wrote, after s_waitcnt vmcnt(0)) and runs all of its <= 4 query tiles.
+#define H2A_SMALL_GROUPS 2
+#define H2A_SMALL_LDS (8 * H2A_SMALL_GROUPS * H2A_GROUP_UNITS * 16)
+__global__ __launch_bounds__(512) void ce_attention_h2_small(const h2_u32x4* __restrict__ qkv, int64_t xs, const int32_t* __restrict__ cu,
+                                                                int n_pairs, h2_u32x2* __restrict__ ctx2, int64_t os,
+                                                                unsigned* __restrict__ flag, int cls_only, int wave_groups) {
+    extern __shared__ __attribute__((aligned(16))) h2_u32x4 h2a_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = blockIdx.x * 8 + w;
+    if (pair >= n_pairs) return;                           // (whole wave; no barrier in this kernel)
+    const int seq = pair / 12, head = pair % 12;
+    const int t0 = cu[seq], S = cu[seq + 1] - t0;
+    const int ng = (S + 31) >> 5;                          // <= H2A_SMALL_GROUPS (the launcher checked max_len)
+    h2_u32x4* const mine = h2a_lds + w * (wave_groups * H2A_GROUP_UNITS);      // (one or two groups per wave: 64 or 128 KB per workgroup)
+    // staging: the wave's eight pieces per group, piece j = (K | V: j >> 2, plane (j >> 1) & 1, key half j & 1)
+    for (int gi = 0; gi < ng; ++gi)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int which = j >> 2, p = (j >> 1) & 1, key = 16 * (j & 1) + (lane >> 2), slot = lane & 3;
+            const int chunk = slot ^ (2 * ((key >> 2) & 1));
+            int k = 32 * gi + key;
+            k = k < S ? k : S - 1;
+            const h2_u32x4* src = qkv + (int64_t)(p * H2A_CHUNKS + 48 * (1 + which) + head * 4 + chunk) * xs + t0 + k;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(mine + gi * H2A_GROUP_UNITS + which * 256 + p * 128 + 64 * (j & 1)),
+                                             16, 0, 0);
+        }
+    const int r = lane & 15, kq = lane >> 4;
+    const int n_tiles = cls_only ? 1 : (S + 15) >> 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const h2_u32x4* kimg = mine + r * 4 + (kq ^ (2 * ((r >> 2) & 1)));
+    const int vq = (lane >> 2) & 3, vpp = lane & 3;
+    const char* vimg = (const char*)(mine + 256 + (4 * kq + vq) * 4 + ((vpp >> 1) ^ (2 * (kq & 1)))) + 8 * (vpp & 1);
+    const int vdi = ((vpp >> 1) ^ (2 * (kq & 1))) & 2 ? -32 : 32;
+    bool bad = false;
+    const int64_t cls_row = cls_only ? seq : -1;
+    if (n_tiles > 2) h2a_tiles<4, 1>(qkv, xs, t0, S, ng, head, 0, n_tiles, kimg, vimg, vdi, r, kq, ctx2, os, cls_row, bad);
+    else if (n_tiles > 1) h2a_tiles<2, 1>(qkv, xs, t0, S, ng, head, 0, n_tiles, kimg, vimg, vdi, r, kq, ctx2, os, cls_row, bad);
+    else h2a_tiles<1, 1>(qkv, xs, t0, S, ng, head, 0, n_tiles, kimg, vimg, vdi, r, kq, ctx2, os, cls_row, bad);
+    if (bad) atomicOr(flag, 1u);
+}
+
 void ce_h2_attention(const void* qkv, int64_t xs, const int32_t* cu, int n_seqs, int max_len, void* ctx2, int64_t os, unsigned* flag,
                      int cls_only, hipStream_t st) {
     const int groups = (max_len + 31) / 32;
+    static const bool no_small = getenv("RR_CE_H2_ATT_NO_SMALL") != nullptr;      // (A/B)
+    if (groups <= H2A_SMALL_GROUPS && !no_small) {
+        const int n_pairs = n_seqs * 12;
+        hipLaunchKernelGGL(ce_attention_h2_small, dim3((unsigned)((n_pairs + 7) / 8)), dim3(512), (size_t)8 * groups * H2A_GROUP_UNITS * 16, st,
+                           (const h2_u32x4*)qkv, xs, cu, n_pairs, (h2_u32x2*)ctx2, os, flag, cls_only, groups);
+        return;
+    }
     const size_t lds = (size_t)(groups < H2A_MAX_GROUPS ? groups : H2A_MAX_GROUPS) * H2A_GROUP_UNITS * 16;
     hipLaunchKernelGGL(ce_attention_h2, dim3((unsigned)n_seqs, 12), dim3(512), lds, st, (const h2_u32x4*)qkv, xs, cu, (h2_u32x2*)ctx2, os, flag,
                        cls_only);
@@ -705,6 +757,7 @@ int ce_h2_set_attributes() {
     H2_ATTR(CE_H2_EPI_GELU_H2);
 #undef H2_ATTR
     RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_h2, hipFuncAttributeMaxDynamicSharedMemorySize, H2A_LDS));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)ce_attention_h2_small, hipFuncAttributeMaxDynamicSharedMemorySize, H2A_SMALL_LDS));
     return RR_OK;
 }
 
